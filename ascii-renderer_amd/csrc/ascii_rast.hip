@@ -1,0 +1,821 @@
+// ascii_rast.hip - MI355X (gfx950) 3D -> ASCII rasterizer: HIP kernels and the C ABI around them.
+//
+// Frame pipeline (all on one HIP stream, nothing leaves HBM between stages):
+//   k_clear          visibility buffer <- (depth 1.0, no triangle)
+//   k_raster         one lane per triangle: vertex transform, near clip, edge setup, cull, cell range;
+//                    small triangles are scanned in place, larger ones are queued as setup records
+//   k_raster_medium  one wavefront per queued record, 8x8 cells per step
+//   k_raster_large   one lane per cell scanning the (short) list of screen-filling records
+//   k_shade          one lane per cell: winner's varyings, Lambert + point lights, RGBA8, depth,
+//                    ramp quantisation (ASCII written here when smoothing is off)
+//   k_ascii          modal smoothing over the quantised grid -> ASCII codes
+// Visibility is resolved with one 64-bit key per cell, (depth bits << 32) | (2*triangle + sub),
+// reduced with unsigned min: smaller depth wins, equal depth goes to the earlier triangle, and the
+// result does not depend on the order in which lanes, waves or kernels reach a cell.
+//
+// Arithmetic follows a fixed contract (binary32 transforms and shading, binary64 edge functions,
+// no fused multiply-add, correctly rounded division and square root) so that the output is
+// reproducible bit for bit; build with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "ascii_rast.h"
+
+namespace {
+
+constexpr uint64_t kBackgroundKey = (uint64_t(0x3F800000u) << 32) | 0xFFFFFFFFull;  // depth 1.0f
+constexpr int kSmallMaxCells = 64;      // cell-range area a single lane scans itself
+constexpr int kMediumMaxCells = 4096;   // above this a record goes to the per-cell pass
+constexpr uint32_t kMediumCapacity = 1u << 18;
+constexpr uint32_t kLargeCapacity = 1u << 14;
+
+enum KernelSlot { K_CLEAR = 0, K_RASTER, K_MEDIUM, K_LARGE, K_SHADE, K_ASCII, K_SLOT6, K_SLOT7 };
+const char *const kKernelNames[AR_N_KERNELS] = {"k_clear",  "k_raster", "k_raster_medium", "k_raster_large",
+                                                "k_shade", "k_ascii",  "",                ""};
+
+// Everything a frame's kernels need besides the big buffers; passed by value as a kernel argument.
+struct FrameParams {
+    float pv[16];  // P*V, column-major
+    float amb[3], ldir[3], lcol[3];
+    float plpos[3 * AR_MAX_POINT_LIGHTS], plcol[3 * AR_MAX_POINT_LIGHTS];
+    int n_pl;
+    int cols, rows;
+    int ya, yb;      // output rows [ya, yb) that are rasterised and shaded (strip + smoothing halo)
+    int row0, row1;  // output rows [row0, row1) whose ASCII codes are written
+    float hw, hh;    // cols/2, rows/2
+    uint32_t n_tris, n_verts;
+    int ramp_len, mode_on, mode_radius, mode_thresh;
+    uint8_t ramp[AR_MAX_RAMP];
+};
+
+// Setup record of one (sub-)triangle: edge functions, per-vertex w and clip z, cell range, key id.
+struct TriRec {
+    double a[3], b[3], c[3];
+    float W[3], Z[3];
+    int i0, i1, j0, j1;  // inclusive cell range, GL window rows (y up)
+    uint32_t id;         // 2*triangle + sub-triangle
+    uint32_t pad;
+};
+
+template <int NV>
+struct Vert {
+    float c[4];                // clip x, y, z, w
+    float v[NV > 0 ? NV : 1];  // varyings (world position, normal, colour) when NV == 9
+};
+
+// gl_Position = uProj * uView * vec4(a_pos, 1) with PV precomputed on the host.
+template <int NV>
+__device__ __forceinline__ Vert<NV> load_vertex(const FrameParams &fp, const float *__restrict__ vbo, uint32_t vi) {
+    const float *p = vbo + size_t(vi) * 9;
+    Vert<NV> o;
+    const float x = p[0], y = p[1], z = p[2];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        o.c[r] = ((fp.pv[0 * 4 + r] * x + fp.pv[1 * 4 + r] * y) + fp.pv[2 * 4 + r] * z) + fp.pv[3 * 4 + r];
+    if (NV > 0) {
+        o.v[0] = x; o.v[1] = y; o.v[2] = z;
+#pragma unroll
+        for (int k = 3; k < NV; k++) o.v[k] = p[k];
+    }
+    return o;
+}
+
+// New vertex on the near plane, always from the inside vertex I towards the outside vertex O, so
+// two triangles sharing the edge compute the identical point.
+template <int NV>
+__device__ __forceinline__ Vert<NV> clip_vertex(const Vert<NV> &I, float dI, const Vert<NV> &O, float dO) {
+    Vert<NV> r;
+    const float t = dI / (dI - dO);
+#pragma unroll
+    for (int k = 0; k < 4; k++) r.c[k] = I.c[k] + (O.c[k] - I.c[k]) * t;
+#pragma unroll
+    for (int k = 0; k < NV; k++) r.v[k] = I.v[k] + (O.v[k] - I.v[k]) * t;
+    return r;
+}
+
+// Near-plane clip (inside: z_c + w_c >= 0).  Returns the number of sub-triangles (0..2) in s0 / s1.
+template <int NV>
+__device__ __forceinline__ int clip_near(const Vert<NV> &in0, const Vert<NV> &in1, const Vert<NV> &in2,
+                                         Vert<NV> (&s0)[3], Vert<NV> (&s1)[3]) {
+    const float d0 = in0.c[2] + in0.c[3], d1 = in1.c[2] + in1.c[3], d2 = in2.c[2] + in2.c[3];
+    const bool b0 = d0 >= 0.0f, b1 = d1 >= 0.0f, b2 = d2 >= 0.0f;
+    const int n_in = int(b0) + int(b1) + int(b2);
+    if (n_in == 0) return 0;
+    if (n_in == 3) {
+        s0[0] = in0; s0[1] = in1; s0[2] = in2;
+        return 1;
+    }
+    // rotate so that A is the odd vertex out: the only inside one, or the only outside one
+    const int a = (n_in == 1) ? (b0 ? 0 : (b1 ? 1 : 2)) : (!b0 ? 0 : (!b1 ? 1 : 2));
+    Vert<NV> A, B, C;
+    float dA, dB, dC;
+    if (a == 0) { A = in0; B = in1; C = in2; dA = d0; dB = d1; dC = d2; }
+    else if (a == 1) { A = in1; B = in2; C = in0; dA = d1; dB = d2; dC = d0; }
+    else { A = in2; B = in0; C = in1; dA = d2; dB = d0; dC = d1; }
+    if (n_in == 1) {
+        s0[0] = A;
+        s0[1] = clip_vertex<NV>(A, dA, B, dB);
+        s0[2] = clip_vertex<NV>(A, dA, C, dC);
+        return 1;
+    }
+    const Vert<NV> pab = clip_vertex<NV>(B, dB, A, dA);
+    const Vert<NV> pca = clip_vertex<NV>(C, dC, A, dA);
+    s0[0] = pab; s0[1] = B; s0[2] = C;
+    s1[0] = pab; s1[1] = C; s1[2] = pca;
+    return 2;
+}
+
+struct Edges {
+    double a[3], b[3], c[3];
+    float W[3], Z[3];
+};
+
+// Edge functions of one (sub-)triangle from its clip coordinates.  False when the triangle cannot
+// produce fragments (non-finite or w <= 0 vertex, back face, zero area).  X, Y receive the
+// pixel-homogeneous vertex coordinates for the caller's cell-range computation.
+__device__ __forceinline__ bool edge_setup(const float (&c0)[4], const float (&c1)[4], const float (&c2)[4], float hw,
+                                           float hh, Edges &e, float (&X)[3], float (&Y)[3]) {
+    bool ok = true;
+#pragma unroll
+    for (int q = 0; q < 4; q++) ok = ok && isfinite(c0[q]) && isfinite(c1[q]) && isfinite(c2[q]);
+    ok = ok && (c0[3] > 0.0f) && (c1[3] > 0.0f) && (c2[3] > 0.0f);
+    if (!ok) return false;
+    e.W[0] = c0[3]; e.W[1] = c1[3]; e.W[2] = c2[3];
+    e.Z[0] = c0[2]; e.Z[1] = c1[2]; e.Z[2] = c2[2];
+    X[0] = (c0[0] + c0[3]) * hw; X[1] = (c1[0] + c1[3]) * hw; X[2] = (c2[0] + c2[3]) * hw;
+    Y[0] = (c0[1] + c0[3]) * hh; Y[1] = (c1[1] + c1[3]) * hh; Y[2] = (c2[1] + c2[3]) * hh;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {  // e_k = v_{k+1} x v_{k+2}
+        const int p = (k + 1) % 3, q = (k + 2) % 3;
+        e.a[k] = double(Y[p]) * double(e.W[q]) - double(Y[q]) * double(e.W[p]);
+        e.b[k] = double(X[q]) * double(e.W[p]) - double(X[p]) * double(e.W[q]);
+        e.c[k] = double(X[p]) * double(Y[q]) - double(X[q]) * double(Y[p]);
+    }
+    const double det = (double(X[0]) * e.a[0] + double(Y[0]) * e.b[0]) + double(e.W[0]) * e.c[0];
+    return det > 0.0;
+}
+
+// Inclusive cell range (GL window coordinates) that contains every covered cell centre, clamped to
+// the viewport columns and to window rows [jlo, jhi].  False when empty.
+__device__ __forceinline__ bool cell_range(const float (&X)[3], const float (&Y)[3], const float (&W)[3], int cols,
+                                           int jlo, int jhi, int &i0, int &i1, int &j0, int &j1) {
+    float minx = X[0] / W[0], maxx = minx, miny = Y[0] / W[0], maxy = miny;
+#pragma unroll
+    for (int k = 1; k < 3; k++) {
+        const float sx = X[k] / W[k], sy = Y[k] / W[k];
+        minx = fminf(minx, sx); maxx = fmaxf(maxx, sx);
+        miny = fminf(miny, sy); maxy = fmaxf(maxy, sy);
+    }
+    const float lox = ceilf(fmaxf(minx - 0.50390625f, 0.0f)), hix = floorf(fminf(maxx - 0.49609375f, float(cols - 1)));
+    const float loy = ceilf(fmaxf(miny - 0.50390625f, float(jlo))), hiy = floorf(fminf(maxy - 0.49609375f, float(jhi)));
+    if (!(lox <= hix) || !(loy <= hiy)) return false;
+    i0 = int(lox); i1 = int(hix); j0 = int(loy); j1 = int(hiy);
+    return true;
+}
+
+__device__ __forceinline__ bool edge_inside(double E, double a, double b) {
+    return E > 0.0 || (E == 0.0 && (a > 0.0 || (a == 0.0 && b > 0.0)));
+}
+
+// Coverage test of cell (i, j) (GL window coordinates) against one record; on a hit f receives the
+// binary32 edge values and zw the window depth.  Depth outside [0, 1) is no hit.
+template <typename R>
+__device__ __forceinline__ bool cover(const R &e, int i, int j, float (&f)[3], float &zw) {
+    const double px = double(i) + 0.5, py = double(j) + 0.5;
+    const double E0 = (e.a[0] * px + e.b[0] * py) + e.c[0];
+    const double E1 = (e.a[1] * px + e.b[1] * py) + e.c[1];
+    const double E2 = (e.a[2] * px + e.b[2] * py) + e.c[2];
+    if (!edge_inside(E0, e.a[0], e.b[0]) || !edge_inside(E1, e.a[1], e.b[1]) || !edge_inside(E2, e.a[2], e.b[2]))
+        return false;
+    f[0] = float(E0); f[1] = float(E1); f[2] = float(E2);
+    const float den = (f[0] * e.W[0] + f[1] * e.W[1]) + f[2] * e.W[2];
+    const float num = (f[0] * e.Z[0] + f[1] * e.Z[1]) + f[2] * e.Z[2];
+    const float zn = num / den;
+    zw = zn * 0.5f + 0.5f;
+    return (zw >= 0.0f) && (zw < 1.0f);
+}
+
+__device__ __forceinline__ uint64_t make_key(float zw, uint32_t id) {
+    return (uint64_t(__float_as_uint(zw)) << 32) | uint64_t(id);
+}
+
+__device__ __forceinline__ void vis_min(uint64_t *vis, size_t cell, uint64_t key) {
+    // the plain load only filters: a stale (larger) value costs one redundant atomic, never a wrong result
+    if (key < vis[cell]) atomicMin(reinterpret_cast<unsigned long long *>(vis + cell), (unsigned long long)key);
+}
+
+__global__ __launch_bounds__(256) void k_clear(uint64_t *__restrict__ vis, size_t first, size_t count) {
+    const size_t n = size_t(blockIdx.x) * 256 + threadIdx.x;
+    const size_t stride = size_t(gridDim.x) * 256;
+    for (size_t p = n; p < count; p += stride) vis[first + p] = kBackgroundKey;
+}
+
+// counters: [0] medium records, [1] large records
+__global__ __launch_bounds__(256) void k_raster(FrameParams fp, const float *__restrict__ vbo,
+                                                const uint32_t *__restrict__ idx, uint64_t *__restrict__ vis,
+                                                TriRec *__restrict__ medium, TriRec *__restrict__ large,
+                                                uint32_t *__restrict__ counters) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= fp.n_tris) return;
+    const uint32_t v0 = idx[3 * size_t(t)], v1 = idx[3 * size_t(t) + 1], v2 = idx[3 * size_t(t) + 2];
+    if (v0 >= fp.n_verts || v1 >= fp.n_verts || v2 >= fp.n_verts) return;
+    const Vert<0> in0 = load_vertex<0>(fp, vbo, v0), in1 = load_vertex<0>(fp, vbo, v1), in2 = load_vertex<0>(fp, vbo, v2);
+    Vert<0> s0[3], s1[3];
+    const int ns = clip_near<0>(in0, in1, in2, s0, s1);
+    const int jlo = fp.rows - fp.yb, jhi = fp.rows - 1 - fp.ya;  // window rows of the rendered strip
+    for (int s = 0; s < ns; s++) {
+        const Vert<0> t0 = s ? s1[0] : s0[0], t1 = s ? s1[1] : s0[1], t2 = s ? s1[2] : s0[2];
+        Edges e;
+        float X[3], Y[3];
+        if (!edge_setup(t0.c, t1.c, t2.c, fp.hw, fp.hh, e, X, Y)) continue;
+        int i0, i1, j0, j1;
+        if (!cell_range(X, Y, e.W, fp.cols, jlo, jhi, i0, i1, j0, j1)) continue;
+        const uint32_t id = 2u * t + uint32_t(s);
+        const int ncells = (i1 - i0 + 1) * (j1 - j0 + 1);
+        if (ncells > kSmallMaxCells) {
+            const bool is_large = ncells > kMediumMaxCells;
+            const uint32_t cap = is_large ? kLargeCapacity : kMediumCapacity;
+            const uint32_t slot = atomicAdd(&counters[is_large ? 1 : 0], 1u);
+            if (slot < cap) {
+                TriRec r;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    r.a[k] = e.a[k]; r.b[k] = e.b[k]; r.c[k] = e.c[k];
+                    r.W[k] = e.W[k]; r.Z[k] = e.Z[k];
+                }
+                r.i0 = i0; r.i1 = i1; r.j0 = j0; r.j1 = j1;
+                r.id = id; r.pad = 0;
+                (is_large ? large : medium)[slot] = r;
+                continue;
+            }
+            // queue full: fall through and scan the range here (slow but correct)
+        }
+        for (int j = j0; j <= j1; j++) {
+            const size_t row = size_t(fp.rows - 1 - j) * fp.cols;
+            for (int i = i0; i <= i1; i++) {
+                float f[3], zw;
+                if (cover(e, i, j, f, zw)) vis_min(vis, row + i, make_key(zw, id));
+            }
+        }
+    }
+}
+
+// One wavefront per queued record; each step covers an 8x8 block of the record's cell range.
+__global__ __launch_bounds__(256) void k_raster_medium(FrameParams fp, uint64_t *__restrict__ vis,
+                                                       const TriRec *__restrict__ medium,
+                                                       const uint32_t *__restrict__ counters) {
+    const uint32_t count = min(counters[0], kMediumCapacity);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * 4u;
+    const int lx = int(lane & 7u), ly = int(lane >> 3);
+    for (uint32_t r = wave; r < count; r += n_waves) {
+        const TriRec &rec = medium[r];
+        const int i0 = rec.i0, i1 = rec.i1, j0 = rec.j0, j1 = rec.j1;
+        for (int by = j0; by <= j1; by += 8) {
+            const int j = by + ly;
+            for (int bx = i0; bx <= i1; bx += 8) {
+                const int i = bx + lx;
+                float f[3], zw;
+                if (i <= i1 && j <= j1 && cover(rec, i, j, f, zw))
+                    vis_min(vis, size_t(fp.rows - 1 - j) * fp.cols + i, make_key(zw, rec.id));
+            }
+        }
+    }
+}
+
+// One lane per cell of a 16x16 tile; every tile walks the list of large records.
+__global__ __launch_bounds__(256) void k_raster_large(FrameParams fp, uint64_t *__restrict__ vis,
+                                                      const TriRec *__restrict__ large,
+                                                      const uint32_t *__restrict__ counters) {
+    const uint32_t count = min(counters[1], kLargeCapacity);
+    if (count == 0) return;
+    const int tx0 = int(blockIdx.x) * 16, ty0 = fp.ya + int(blockIdx.y) * 16;  // output (top-down) rows
+    const int i = tx0 + int(threadIdx.x & 15u), r = ty0 + int(threadIdx.x >> 4);
+    const int j = fp.rows - 1 - r;
+    const int tj1 = fp.rows - 1 - ty0, tj0 = tj1 - 15;  // the tile's window-row span
+    const bool live = (i < fp.cols) && (r < fp.yb);
+    uint64_t best = kBackgroundKey;
+    for (uint32_t k = 0; k < count; k++) {
+        const TriRec &rec = large[k];
+        if (rec.i1 < tx0 || rec.i0 > tx0 + 15 || rec.j1 < tj0 || rec.j0 > tj1) continue;  // wave-uniform
+        float f[3], zw;
+        if (live && i >= rec.i0 && i <= rec.i1 && j >= rec.j0 && j <= rec.j1 && cover(rec, i, j, f, zw)) {
+            const uint64_t key = make_key(zw, rec.id);
+            best = key < best ? key : best;
+        }
+    }
+    if (live && best != kBackgroundKey) vis_min(vis, size_t(r) * fp.cols + i, best);
+}
+
+__device__ __forceinline__ int ramp_index(int r, int g, int b, int ramp_len) {
+    // == clamp(round(((r+g+b)/3/255) * (L-1)), 0, L-1): the rounded value is never a tie
+    return (2 * (r + g + b) * (ramp_len - 1) + 765) / 1530;
+}
+
+// raster_shader.js:42-62 in binary32.
+__device__ __forceinline__ void shade(const FrameParams &fp, const float (&v)[9], uint8_t (&out)[4]) {
+    const float len2 = (v[3] * v[3] + v[4] * v[4]) + v[5] * v[5];
+    const float inv = (len2 > 0.0f) ? 1.0f / sqrtf(len2) : 0.0f;
+    const float N[3] = {v[3] * inv, v[4] * inv, v[5] * inv};
+    float col[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) col[k] = v[6 + k] * fp.amb[k];
+    const float ndl = fmaxf((N[0] * (-fp.ldir[0]) + N[1] * (-fp.ldir[1])) + N[2] * (-fp.ldir[2]), 0.0f);
+#pragma unroll
+    for (int k = 0; k < 3; k++) col[k] = col[k] + (v[6 + k] * fp.lcol[k]) * ndl;
+    for (int i = 0; i < AR_MAX_POINT_LIGHTS; i++) {
+        if (i >= fp.n_pl) break;
+        const float lv[3] = {fp.plpos[3 * i] - v[0], fp.plpos[3 * i + 1] - v[1], fp.plpos[3 * i + 2] - v[2]};
+        const float d2 = fmaxf((lv[0] * lv[0] + lv[1] * lv[1]) + lv[2] * lv[2], 1e-4f);
+        const float il = 1.0f / sqrtf(d2);
+        const float Ld[3] = {lv[0] * il, lv[1] * il, lv[2] * il};
+        const float ndlp = fmaxf((N[0] * Ld[0] + N[1] * Ld[1]) + N[2] * Ld[2], 0.0f);
+        const float atten = 1.0f / (1.0f + d2 * 0.05f);
+        const float w = ndlp * atten;
+#pragma unroll
+        for (int k = 0; k < 3; k++) col[k] = col[k] + (v[6 + k] * fp.plcol[3 * i + k]) * w;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float c = fminf(fmaxf(col[k], 0.0f), 1.0f);
+        out[k] = uint8_t(int(floorf(c * 255.0f + 0.5f)));
+    }
+    out[3] = 255;
+}
+
+// One lane per cell of output rows [ya, yb): rebuild the winner's setup, interpolate, shade, store.
+__global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__restrict__ vbo,
+                                               const uint32_t *__restrict__ idx, const uint64_t *__restrict__ vis,
+                                               uint8_t *__restrict__ rgba, float *__restrict__ depth,
+                                               uint8_t *__restrict__ ascii) {
+    const size_t n = size_t(fp.yb - fp.ya) * fp.cols;
+    const size_t p = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p >= n) return;
+    const size_t cell = size_t(fp.ya) * fp.cols + p;
+    const int r = int(cell / fp.cols), i = int(cell - size_t(r) * fp.cols);
+    const int j = fp.rows - 1 - r;
+    const uint64_t key = vis[cell];
+    uint8_t px[4] = {0, 0, 0, 255};
+    float zw = 1.0f;
+    if (key != kBackgroundKey) {
+        const uint32_t id = uint32_t(key), t = id >> 1, sub = id & 1u;
+        const uint32_t v0 = idx[3 * size_t(t)], v1 = idx[3 * size_t(t) + 1], v2 = idx[3 * size_t(t) + 2];
+        const Vert<9> in0 = load_vertex<9>(fp, vbo, v0), in1 = load_vertex<9>(fp, vbo, v1), in2 = load_vertex<9>(fp, vbo, v2);
+        Vert<9> s0[3], s1[3];
+        clip_near<9>(in0, in1, in2, s0, s1);
+        const Vert<9> t0 = sub ? s1[0] : s0[0], t1 = sub ? s1[1] : s0[1], t2 = sub ? s1[2] : s0[2];
+        Edges e;
+        float X[3], Y[3], f[3];
+        edge_setup(t0.c, t1.c, t2.c, fp.hw, fp.hh, e, X, Y);
+        cover(e, i, j, f, zw);  // same expressions as the raster pass: reproduces its f and depth
+        const float rS = 1.0f / ((f[0] + f[1]) + f[2]);
+        const float b0 = f[0] * rS, b1 = f[1] * rS, b2 = f[2] * rS;
+        float v[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++) v[q] = (b0 * t0.v[q] + b1 * t1.v[q]) + b2 * t2.v[q];
+        shade(fp, v, px);
+    }
+    *reinterpret_cast<uint32_t *>(rgba + cell * 4) =
+        uint32_t(px[0]) | (uint32_t(px[1]) << 8) | (uint32_t(px[2]) << 16) | (uint32_t(px[3]) << 24);
+    depth[cell] = zw;
+    if (!fp.mode_on && r >= fp.row0 && r < fp.row1) ascii[cell] = fp.ramp[ramp_index(px[0], px[1], px[2], fp.ramp_len)];
+}
+
+// ASCII stage over an RGBA8 grid: alpha 2..254 is a literal code, otherwise ramp quantisation with
+// optional modal smoothing (ascii_pass_shader.js:77-138,153-188).  One lane per cell of rows [row0,row1).
+__global__ __launch_bounds__(256) void k_ascii(FrameParams fp, const uint8_t *__restrict__ rgba,
+                                               uint8_t *__restrict__ ascii) {
+    const size_t n = size_t(fp.row1 - fp.row0) * fp.cols;
+    const size_t p = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p >= n) return;
+    const size_t cell = size_t(fp.row0) * fp.cols + p;
+    const int y = int(cell / fp.cols), x = int(cell - size_t(y) * fp.cols);
+    const uint32_t *px = reinterpret_cast<const uint32_t *>(rgba);
+    const uint32_t me = px[cell];
+    const int a = int(me >> 24);
+    if (a >= 2 && a <= 254) { ascii[cell] = uint8_t(a); return; }
+    const int base = ramp_index(int(me & 255u), int((me >> 8) & 255u), int((me >> 16) & 255u), fp.ramp_len);
+    int fin = base;
+    if (fp.mode_on == 1) {
+        int radius = fp.mode_radius;
+        radius = radius < 1 ? 1 : (radius > 3 ? 3 : radius);
+        int cand = -1, cnt = 0, votes = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1 && cand < 0) break;
+            for (int dy = -radius; dy <= radius; dy++) {
+                const int ny = min(max(y + dy, 0), fp.rows - 1);
+                for (int dx = -radius; dx <= radius; dx++) {
+                    if (dx == 0 && dy == 0) continue;
+                    const int nx = min(max(x + dx, 0), fp.cols - 1);
+                    const uint32_t q = px[size_t(ny) * fp.cols + nx];
+                    const int qa = int(q >> 24);
+                    if (qa >= 2 && qa <= 254) continue;
+                    const int ni = ramp_index(int(q & 255u), int((q >> 8) & 255u), int((q >> 16) & 255u), fp.ramp_len);
+                    if (pass == 0) {
+                        if (cnt == 0) { cand = ni; cnt = 1; }
+                        else if (ni == cand) cnt += 1;
+                        else cnt -= 1;
+                    } else if (ni == cand) votes += 1;
+                }
+            }
+        }
+        if (cand >= 0 && votes >= fp.mode_thresh && cand != base) fin = cand;
+    }
+    ascii[cell] = (fin >= 0 && fin < fp.ramp_len) ? fp.ramp[fin] : uint8_t(32);
+}
+
+thread_local char g_create_error[256] = "";
+
+}  // namespace
+
+struct ar_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    float *d_vbo = nullptr;
+    uint32_t *d_idx = nullptr;
+    uint32_t n_verts = 0, n_tris = 0;
+    float proj[16], view[16];
+    FrameParams fp;
+    int strip0 = 0, strip1 = 0;
+    int cols = 0, rows = 0;  // size of the current targets
+    uint64_t *d_vis = nullptr;
+    uint8_t *d_rgba = nullptr;
+    float *d_depth = nullptr;
+    uint8_t *d_ascii = nullptr;
+    TriRec *d_medium = nullptr, *d_large = nullptr;
+    uint32_t *d_counters = nullptr;
+    uint32_t *h_counters = nullptr;  // pinned
+    uint8_t *d_q_rgba = nullptr, *d_q_ascii = nullptr;
+    size_t q_cells = 0;
+    bool rendered = false;
+    bool profiling = false;
+    struct Stamp { hipEvent_t a, b; int slot; };
+    std::vector<Stamp> stamps;
+    std::vector<hipEvent_t> free_events;
+    char err[256] = "";
+};
+
+namespace {
+
+int fail(ar_ctx *ctx, int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx ? ctx->err : g_create_error, 256, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define AR_HIP(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) return fail(ctx, AR_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+void matmul_pv(const float *P, const float *V, float *PV) {
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++)
+            PV[c * 4 + r] = ((P[0 * 4 + r] * V[c * 4 + 0] + P[1 * 4 + r] * V[c * 4 + 1]) + P[2 * 4 + r] * V[c * 4 + 2]) +
+                            P[3 * 4 + r] * V[c * 4 + 3];
+}
+
+struct Stamper {  // brackets one launch with events when profiling is on
+    ar_ctx *ctx;
+    hipEvent_t a = nullptr, b = nullptr;
+    int slot;
+    Stamper(ar_ctx *c, int s) : ctx(c), slot(s) {
+        if (!ctx->profiling) return;
+        a = take(); b = take();
+        if (a) (void)hipEventRecord(a, ctx->stream);
+    }
+    ~Stamper() {
+        if (!ctx->profiling || !a || !b) return;
+        (void)hipEventRecord(b, ctx->stream);
+        ctx->stamps.push_back({a, b, slot});
+    }
+    hipEvent_t take() {
+        if (!ctx->free_events.empty()) { hipEvent_t e = ctx->free_events.back(); ctx->free_events.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+    }
+};
+
+int free_targets(ar_ctx *ctx) {
+    (void)hipFree(ctx->d_vis); (void)hipFree(ctx->d_rgba); (void)hipFree(ctx->d_depth); (void)hipFree(ctx->d_ascii);
+    ctx->d_vis = nullptr; ctx->d_rgba = nullptr; ctx->d_depth = nullptr; ctx->d_ascii = nullptr;
+    ctx->cols = ctx->rows = 0;
+    ctx->rendered = false;
+    return 0;
+}
+
+int ensure_targets(ar_ctx *ctx, int cols, int rows) {
+    if (ctx->d_vis && ctx->cols == cols && ctx->rows == rows) return 0;
+    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_targets(ctx);
+    const size_t n = size_t(cols) * rows;
+    AR_HIP(ctx, hipMalloc(&ctx->d_vis, n * sizeof(uint64_t)));
+    AR_HIP(ctx, hipMalloc(&ctx->d_rgba, n * 4));
+    AR_HIP(ctx, hipMalloc(&ctx->d_depth, n * sizeof(float)));
+    AR_HIP(ctx, hipMalloc(&ctx->d_ascii, n));
+    // rows outside a strip are never written by the kernels: give them defined contents once
+    AR_HIP(ctx, hipMemsetAsync(ctx->d_rgba, 0, n * 4, ctx->stream));
+    AR_HIP(ctx, hipMemsetAsync(ctx->d_depth, 0, n * sizeof(float), ctx->stream));
+    AR_HIP(ctx, hipMemsetAsync(ctx->d_ascii, 0, n, ctx->stream));
+    ctx->cols = cols; ctx->rows = rows;
+    return 0;
+}
+
+int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
+    if (cols <= 0 || rows <= 0 || size_t(cols) * rows > (size_t(1) << 31))
+        return fail(ctx, AR_E_ARG, "ar_render: bad grid %d x %d", cols, rows);
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_targets(ctx, cols, rows);
+    if (rc) return rc;
+    if (ctx->n_tris == 0 || !ctx->d_vbo || !ctx->d_idx) return 0;  // raster.js:274: nothing to draw
+
+    FrameParams &fp = ctx->fp;
+    fp.cols = cols; fp.rows = rows;
+    fp.hw = float(cols) * 0.5f; fp.hh = float(rows) * 0.5f;
+    fp.n_tris = ctx->n_tris; fp.n_verts = ctx->n_verts;
+    int row0 = 0, row1 = rows;
+    if (ctx->strip1 > ctx->strip0) {
+        if (ctx->strip1 > rows) return fail(ctx, AR_E_ARG, "strip [%d,%d) exceeds %d rows", ctx->strip0, ctx->strip1, rows);
+        row0 = ctx->strip0; row1 = ctx->strip1;
+    }
+    const int halo = fp.mode_on == 1 ? 3 : 0;  // smoothing reads up to 3 rows beyond the strip
+    fp.row0 = row0; fp.row1 = row1;
+    fp.ya = row0 - halo < 0 ? 0 : row0 - halo;
+    fp.yb = row1 + halo > rows ? rows : row1 + halo;
+    matmul_pv(ctx->proj, ctx->view, fp.pv);
+
+    const size_t strip_cells = size_t(fp.yb - fp.ya) * cols;
+    const unsigned cell_blocks = unsigned((strip_cells + 255) / 256);
+    AR_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+    {
+        Stamper s(ctx, K_CLEAR);
+        const unsigned blocks = cell_blocks < 2048u ? cell_blocks : 2048u;
+        k_clear<<<blocks, 256, 0, ctx->stream>>>(ctx->d_vis, size_t(fp.ya) * cols, strip_cells);
+    }
+    {
+        Stamper s(ctx, K_RASTER);
+        k_raster<<<(fp.n_tris + 255) / 256, 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_vis, ctx->d_medium,
+                                                                  ctx->d_large, ctx->d_counters);
+    }
+    {
+        Stamper s(ctx, K_MEDIUM);
+        k_raster_medium<<<1024, 256, 0, ctx->stream>>>(fp, ctx->d_vis, ctx->d_medium, ctx->d_counters);
+    }
+    {
+        Stamper s(ctx, K_LARGE);
+        dim3 grid((cols + 15) / 16, (fp.yb - fp.ya + 15) / 16);
+        k_raster_large<<<grid, 256, 0, ctx->stream>>>(fp, ctx->d_vis, ctx->d_large, ctx->d_counters);
+    }
+    {
+        Stamper s(ctx, K_SHADE);
+        k_shade<<<cell_blocks, 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_vis, ctx->d_rgba, ctx->d_depth,
+                                                     ctx->d_ascii);
+    }
+    if (fp.mode_on == 1) {
+        Stamper s(ctx, K_ASCII);
+        const size_t out_cells = size_t(row1 - row0) * cols;
+        k_ascii<<<unsigned((out_cells + 255) / 256), 256, 0, ctx->stream>>>(fp, ctx->d_rgba, ctx->d_ascii);
+    }
+    AR_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    AR_HIP(ctx, hipGetLastError());
+    ctx->rendered = true;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+ar_ctx *ar_create(int device_id) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { fail(nullptr, AR_E_HIP, "no HIP device available (%s)", hipGetErrorString(e)); return nullptr; }
+    if (device_id < 0 || device_id >= n) { fail(nullptr, AR_E_ARG, "device %d out of range (0..%d)", device_id, n - 1); return nullptr; }
+    ar_ctx *ctx = new (std::nothrow) ar_ctx();
+    if (!ctx) { fail(nullptr, AR_E_NOMEM, "out of host memory"); return nullptr; }
+    ctx->device = device_id;
+    bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc(&ctx->d_medium, size_t(kMediumCapacity) * sizeof(TriRec)) == hipSuccess &&
+              hipMalloc(&ctx->d_large, size_t(kLargeCapacity) * sizeof(TriRec)) == hipSuccess &&
+              hipMalloc(&ctx->d_counters, 4 * sizeof(uint32_t)) == hipSuccess &&
+              hipHostMalloc(&ctx->h_counters, 4 * sizeof(uint32_t)) == hipSuccess;
+    if (!ok) {
+        fail(nullptr, AR_E_HIP, "context setup failed: %s", hipGetErrorString(hipGetLastError()));
+        ar_destroy(ctx);
+        return nullptr;
+    }
+    memset(ctx->h_counters, 0, 4 * sizeof(uint32_t));
+    memset(&ctx->fp, 0, sizeof ctx->fp);
+    static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    memcpy(ctx->proj, ident, sizeof ident);
+    memcpy(ctx->view, ident, sizeof ident);
+    // defaults of the reference: raster.js:66-68, config.js:15,26-34 with ascii_pass.js:149-152
+    const float amb[3] = {0.15f, 0.18f, 0.22f}, dir[3] = {0.25f, -1.0f, 0.15f}, col[3] = {1.2f, 1.15f, 1.1f};
+    ar_set_lights(ctx, amb, dir, col, 0, nullptr, nullptr);
+    ar_set_ascii(ctx, reinterpret_cast<const uint8_t *>("@%#*+=-:. "), 10, 1, 2, 12);
+    return ctx;
+}
+
+void ar_destroy(ar_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &s : ctx->stamps) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    for (auto e : ctx->free_events) (void)hipEventDestroy(e);
+    free_targets(ctx);
+    (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx);
+    (void)hipFree(ctx->d_medium); (void)hipFree(ctx->d_large); (void)hipFree(ctx->d_counters);
+    (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii);
+    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *ar_last_error(ar_ctx *ctx) { return ctx ? ctx->err : g_create_error; }
+
+int ar_set_mesh(ar_ctx *ctx, const float *vbo9, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris) {
+    if (!ctx) return AR_E_ARG;
+    if (n_tris > 0x7FFFFFFFu) return fail(ctx, AR_E_ARG, "ar_set_mesh: too many triangles (%u)", n_tris);
+    if (n_tris && (!vbo9 || !idx || !n_verts)) return fail(ctx, AR_E_ARG, "ar_set_mesh: null buffer with %u triangles", n_tris);
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx);
+    ctx->d_vbo = nullptr; ctx->d_idx = nullptr; ctx->n_verts = 0; ctx->n_tris = 0;
+    if (!n_tris) return 0;
+    AR_HIP(ctx, hipMalloc(&ctx->d_vbo, size_t(n_verts) * 9 * sizeof(float)));
+    AR_HIP(ctx, hipMalloc(&ctx->d_idx, size_t(n_tris) * 3 * sizeof(uint32_t)));
+    AR_HIP(ctx, hipMemcpy(ctx->d_vbo, vbo9, size_t(n_verts) * 9 * sizeof(float), hipMemcpyHostToDevice));
+    AR_HIP(ctx, hipMemcpy(ctx->d_idx, idx, size_t(n_tris) * 3 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    ctx->n_verts = n_verts; ctx->n_tris = n_tris;
+    return 0;
+}
+
+int ar_set_camera(ar_ctx *ctx, const float proj[16], const float view[16]) {
+    if (!ctx) return AR_E_ARG;
+    if (!proj || !view) return fail(ctx, AR_E_ARG, "ar_set_camera: null matrix");
+    memcpy(ctx->proj, proj, 16 * sizeof(float));
+    memcpy(ctx->view, view, 16 * sizeof(float));
+    return 0;
+}
+
+int ar_set_lights(ar_ctx *ctx, const float amb[3], const float dir[3], const float dircol[3], int n_pl,
+                  const float *plpos, const float *plcol) {
+    if (!ctx) return AR_E_ARG;
+    if (!amb || !dir || !dircol) return fail(ctx, AR_E_ARG, "ar_set_lights: null vector");
+    if (n_pl < 0 || n_pl > AR_MAX_POINT_LIGHTS || (n_pl && (!plpos || !plcol)))
+        return fail(ctx, AR_E_ARG, "ar_set_lights: bad point-light count %d", n_pl);
+    FrameParams &fp = ctx->fp;
+    for (int k = 0; k < 3; k++) { fp.amb[k] = amb[k]; fp.ldir[k] = dir[k]; fp.lcol[k] = dircol[k]; }
+    memset(fp.plpos, 0, sizeof fp.plpos);
+    memset(fp.plcol, 0, sizeof fp.plcol);
+    for (int k = 0; k < 3 * n_pl; k++) { fp.plpos[k] = plpos[k]; fp.plcol[k] = plcol[k]; }
+    fp.n_pl = n_pl;
+    return 0;
+}
+
+int ar_set_ascii(ar_ctx *ctx, const uint8_t *ramp, int ramp_len, int mode_on, int mode_radius, int mode_thresh) {
+    if (!ctx) return AR_E_ARG;
+    if (!ramp || ramp_len < 1 || ramp_len > AR_MAX_RAMP) return fail(ctx, AR_E_ARG, "ar_set_ascii: ramp length %d not in 1..%d", ramp_len, AR_MAX_RAMP);
+    FrameParams &fp = ctx->fp;
+    memset(fp.ramp, 32, sizeof fp.ramp);
+    memcpy(fp.ramp, ramp, size_t(ramp_len));
+    fp.ramp_len = ramp_len;
+    fp.mode_on = mode_on ? 1 : 0;
+    fp.mode_radius = mode_radius;
+    fp.mode_thresh = mode_thresh;
+    return 0;
+}
+
+int ar_set_strip(ar_ctx *ctx, int row0, int row1) {
+    if (!ctx) return AR_E_ARG;
+    if (row0 < 0 || row1 < row0) return fail(ctx, AR_E_ARG, "ar_set_strip: bad rows [%d,%d)", row0, row1);
+    ctx->strip0 = row0; ctx->strip1 = row1;
+    return 0;
+}
+
+int ar_render_async(ar_ctx *ctx, int cols, int rows) {
+    if (!ctx) return AR_E_ARG;
+    return enqueue_frame(ctx, cols, rows);
+}
+
+int ar_sync(ar_ctx *ctx) {
+    if (!ctx) return AR_E_ARG;
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ar_read(ar_ctx *ctx, uint8_t *rgba, float *depth, uint8_t *ascii, uint32_t *ids) {
+    if (!ctx) return AR_E_ARG;
+    if (!ctx->rendered) return fail(ctx, AR_E_STATE, "ar_read: no frame has been rendered at this grid size");
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t n = size_t(ctx->cols) * ctx->rows;
+    if (rgba) AR_HIP(ctx, hipMemcpy(rgba, ctx->d_rgba, n * 4, hipMemcpyDeviceToHost));
+    if (depth) AR_HIP(ctx, hipMemcpy(depth, ctx->d_depth, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (ascii) AR_HIP(ctx, hipMemcpy(ascii, ctx->d_ascii, n, hipMemcpyDeviceToHost));
+    if (ids) {
+        std::vector<uint64_t> keys(n);
+        AR_HIP(ctx, hipMemcpy(keys.data(), ctx->d_vis, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        for (size_t p = 0; p < n; p++) ids[p] = uint32_t(keys[p]);
+    }
+    return 0;
+}
+
+int ar_render(ar_ctx *ctx, int cols, int rows, uint8_t *rgba, float *depth, uint8_t *ascii) {
+    if (!ctx) return AR_E_ARG;
+    int rc = enqueue_frame(ctx, cols, rows);
+    if (rc) return rc;
+    if (ctx->n_tris == 0 || !ctx->rendered) return ar_sync(ctx);  // no geometry: outputs stay untouched (raster.js:274)
+    return ar_read(ctx, rgba, depth, ascii, nullptr);
+}
+
+void *ar_device_buffer(ar_ctx *ctx, int which) {
+    if (!ctx) return nullptr;
+    switch (which) {
+        case 0: return ctx->d_rgba;
+        case 1: return ctx->d_depth;
+        case 2: return ctx->d_ascii;
+        default: return nullptr;
+    }
+}
+
+void *ar_stream(ar_ctx *ctx) { return ctx ? ctx->stream : nullptr; }
+
+int ar_quantize(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *ascii) {
+    if (!ctx) return AR_E_ARG;
+    if (!rgba || !ascii || cols <= 0 || rows <= 0 || size_t(cols) * rows > (size_t(1) << 31))
+        return fail(ctx, AR_E_ARG, "ar_quantize: bad arguments (%d x %d)", cols, rows);
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = size_t(cols) * rows;
+    if (n > ctx->q_cells) {
+        AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii);
+        ctx->d_q_rgba = nullptr; ctx->d_q_ascii = nullptr; ctx->q_cells = 0;
+        AR_HIP(ctx, hipMalloc(&ctx->d_q_rgba, n * 4));
+        AR_HIP(ctx, hipMalloc(&ctx->d_q_ascii, n));
+        ctx->q_cells = n;
+    }
+    FrameParams fp = ctx->fp;
+    fp.cols = cols; fp.rows = rows; fp.row0 = 0; fp.row1 = rows; fp.ya = 0; fp.yb = rows;
+    AR_HIP(ctx, hipMemcpyAsync(ctx->d_q_rgba, rgba, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    {
+        Stamper s(ctx, K_ASCII);
+        k_ascii<<<unsigned((n + 255) / 256), 256, 0, ctx->stream>>>(fp, ctx->d_q_rgba, ctx->d_q_ascii);
+    }
+    AR_HIP(ctx, hipGetLastError());
+    AR_HIP(ctx, hipMemcpyAsync(ascii, ctx->d_q_ascii, n, hipMemcpyDeviceToHost, ctx->stream));
+    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ar_set_profiling(ar_ctx *ctx, int on) {
+    if (!ctx) return AR_E_ARG;
+    ctx->profiling = on != 0;
+    return 0;
+}
+
+int ar_kernel_stats(ar_ctx *ctx, const char *names[AR_N_KERNELS], uint32_t launches[AR_N_KERNELS], float total_ms[AR_N_KERNELS]) {
+    if (!ctx) return AR_E_ARG;
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < AR_N_KERNELS; k++) {
+        if (names) names[k] = kKernelNames[k];
+        if (launches) launches[k] = 0;
+        if (total_ms) total_ms[k] = 0.0f;
+    }
+    for (auto &s : ctx->stamps) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            if (launches) launches[s.slot] += 1;
+            if (total_ms) total_ms[s.slot] += ms;
+        }
+        ctx->free_events.push_back(s.a);
+        ctx->free_events.push_back(s.b);
+    }
+    ctx->stamps.clear();
+    return 0;
+}
+
+int ar_frame_counters(ar_ctx *ctx, uint32_t out[4]) {
+    if (!ctx || !out) return AR_E_ARG;
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out[0] = ctx->n_tris;
+    out[1] = ctx->h_counters[0];
+    out[2] = ctx->h_counters[1];
+    out[3] = 0;
+    return 0;
+}
+
+}  // extern "C"

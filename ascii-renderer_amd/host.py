@@ -1,0 +1,304 @@
+"""Host half of the raster backend, as Python, for the pytest / bench harness.
+
+The product's host side is JavaScript (ascii-renderer_amd/js/hip_backend.js); this module mirrors the
+same reference logic so Python tests and bench.py can feed the C-ABI library with identical inputs:
+
+  camera_matrices  <- mat4Perspective / mat4LookAt / yawPitchToDir and the aspect / fov logic
+                      (js/render/backends/raster.js:15-45, 284-301)
+  pack_lights      <- light uniform packing (raster.js:66-68, 307-342)
+  build_geometry   <- RasterBackend._rebuildGeometry + _resolveColor (raster.js:135-266)
+
+All arithmetic is binary64 and only the final store rounds to binary32, as the reference's
+Float32Array / gl.uniform* stores do.
+"""
+import math
+
+import numpy as np
+
+MAX_POINT_LIGHTS = 8                      # raster_shader.js:5
+DEFAULT_AMBIENT = (0.15, 0.18, 0.22)      # raster.js:66
+DEFAULT_LIGHT_DIR = (0.25, -1.0, 0.15)    # raster.js:67 (not normalized, reproduced as is)
+DEFAULT_LIGHT_COLOR = (1.2, 1.15, 1.1)    # raster.js:68
+LEGACY_COLORS = {0: (5, 5, 5), 1: (0.9, 0.9, 0.9), 2: (0.7, 0.9, 0.7), 3: (0.95, 0.45, 0.45), 6: (0.9, 0.95, 1.0)}
+FALLBACK_COLOR = (0.8, 0.8, 0.8)
+SPHERE_LAT, SPHERE_LON = 12, 16           # raster.js:197
+PLANE_HALF_SIZE = 20.0                    # raster.js:187
+
+
+def _is_finite_number(v):
+    return isinstance(v, (int, float)) and not isinstance(v, bool) and math.isfinite(v)
+
+
+def _truthy(v):
+    """JavaScript truthiness for the value kinds a scene object holds."""
+    if v is None or v is False:
+        return False
+    if isinstance(v, (int, float)):
+        return v != 0 and not (isinstance(v, float) and math.isnan(v))
+    if isinstance(v, str):
+        return len(v) > 0
+    return True
+
+
+def _or(v, default):
+    return v if _truthy(v) else default
+
+
+def _hypot3(x, y, z):
+    return math.hypot(x, y, z)
+
+
+def _normalize(v):
+    length = _hypot3(*v) or 1.0
+    return (v[0] / length, v[1] / length, v[2] / length)
+
+
+def _cross(a, b):
+    return (a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0])
+
+
+def _dot(a, b):
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]
+
+
+def mat4_perspective(fovy_rad, aspect, near, far):
+    """raster.js:15-22 (column-major)."""
+    f = 1.0 / math.tan(max(1e-6, fovy_rad * 0.5))
+    nf = 1.0 / (near - far)
+    out = np.zeros(16, dtype=np.float32)
+    out[0] = f / aspect
+    out[5] = f
+    out[10] = (far + near) * nf
+    out[11] = -1.0
+    out[14] = 2.0 * far * near * nf
+    return out
+
+
+def yaw_pitch_to_dir(yaw, pitch):
+    """raster.js:41-45: yaw = pitch = 0 looks along +X."""
+    cp, sp = math.cos(pitch), math.sin(pitch)
+    cy, sy = math.cos(yaw), math.sin(yaw)
+    return (cp * cy, sp, cp * sy)
+
+
+def mat4_look_at(eye, center, up):
+    """raster.js:30-39 (column-major)."""
+    f = _normalize((center[0] - eye[0], center[1] - eye[1], center[2] - eye[2]))
+    s = _normalize(_cross(f, up))
+    u = _cross(s, f)
+    out = np.zeros(16, dtype=np.float32)
+    out[0], out[1], out[2] = s[0], u[0], -f[0]
+    out[4], out[5], out[6] = s[1], u[1], -f[1]
+    out[8], out[9], out[10] = s[2], u[2], -f[2]
+    out[12], out[13], out[14], out[15] = -_dot(s, eye), -_dot(u, eye), _dot(f, eye), 1.0
+    return out
+
+
+def camera_matrices(cam, cols, rows, pixel_aspect=None, fovy_deg=80.0):
+    """(proj, view) exactly as RasterBackend.render uploads them (raster.js:284-304).
+
+    cam: {'pos': (x, y, z), 'yaw': rad, 'pitch': rad}.  pixel_aspect None means
+    config.PATH_TRACER.PIXEL_ASPECT is unset (1.0).  The reference reads a config key that does not
+    exist, so its field of view is always the literal 80 degrees (raster.js:297).
+    """
+    w, h = int(cols), int(rows)
+    eye = tuple(float(v) for v in cam["pos"])
+    d = yaw_pitch_to_dir(cam.get("yaw", 0.0) or 0.0, cam.get("pitch", 0.0) or 0.0)
+    center = (eye[0] + d[0], eye[1] + d[1], eye[2] + d[2])
+    pix = max(1e-6, pixel_aspect) if (pixel_aspect is not None and math.isfinite(pixel_aspect)) else 1.0
+    fov = (fovy_deg or 80) * math.pi / 180
+    aspect = max(1e-6, (w / max(1, h)) * pix)
+    return mat4_perspective(fov, aspect, 0.05, 100.0), mat4_look_at(eye, center, (0.0, 1.0, 0.0))
+
+
+def _idx_or(seq, i, default):
+    """JS `seq?.[i] || default`."""
+    try:
+        v = seq[i] if seq is not None else None
+    except (IndexError, KeyError, TypeError):
+        v = None
+    return _or(v, default)
+
+
+def pack_lights(scene):
+    """Light uniforms as raster.js:307-342 computes them.
+
+    Returns {'ambient','dir','dir_color': float32[3], 'pl_pos','pl_col': float32[n,3], n <= 8}.
+    """
+    scene = scene or {}
+    lights = scene.get("lights") or None
+    ambient, ldir, lcol = DEFAULT_AMBIENT, DEFAULT_LIGHT_DIR, DEFAULT_LIGHT_COLOR
+    if lights and _truthy(lights.get("env")):
+        e = lights["env"]
+        k = _or(e.get("intensity"), 0)
+        ambient = tuple(_idx_or(e.get("color"), i, 0) * k for i in range(3))
+    elif _truthy((scene.get("envLight") or {}).get("color")):
+        ambient = scene["envLight"]["color"]
+    if lights and lights.get("directionals"):
+        d0 = lights["directionals"][0]
+        ldir = _or(d0.get("dir"), ldir)
+        k = _or(d0.get("intensity"), 0)
+        lcol = tuple(_idx_or(d0.get("color"), i, 1) * k for i in range(3))
+    elif _truthy((scene.get("dirLight") or {}).get("dir")):
+        ldir = scene["dirLight"]["dir"]
+        lcol = _or(scene["dirLight"].get("color"), lcol)
+    pts = (lights or {}).get("points") or []
+    n = min(MAX_POINT_LIGHTS, len(pts))
+    pl_pos = np.zeros((n, 3), dtype=np.float32)
+    pl_col = np.zeros((n, 3), dtype=np.float32)
+    for i in range(n):
+        p = _or(pts[i].get("p"), (0, 0, 0))
+        c = _or(pts[i].get("color"), (1, 1, 1))
+        k = pts[i].get("intensity")
+        k = float(k) if _is_finite_number(k) and k != 0 else 0.0
+        pl_pos[i] = (p[0], p[1], p[2])
+        pl_col[i] = (c[0] * k, c[1] * k, c[2] * k)
+    return {
+        "ambient": np.asarray(ambient[:3], dtype=np.float32),
+        "dir": np.asarray(ldir[:3], dtype=np.float32),
+        "dir_color": np.asarray(lcol[:3], dtype=np.float32),
+        "pl_pos": pl_pos,
+        "pl_col": pl_col,
+    }
+
+
+def _clamp01(v):
+    return min(1.0, max(0.0, v))
+
+
+def _num_or_zero(v):
+    """JS `+v || 0` for JSON-able values."""
+    if isinstance(v, bool):
+        return 1.0 if v else 0.0
+    if isinstance(v, (int, float)):
+        return 0.0 if (v != v) else float(v)
+    return 0.0
+
+
+def resolve_color(scene, mat=None, m=None):
+    """raster.js:135-146."""
+    mats = scene.get("materials") if scene else None
+    if isinstance(mats, (list, tuple)) and _is_finite_number(mat):
+        i = int(mat)                      # JS `mat|0` truncates toward zero
+        M = mats[i] if 0 <= i < len(mats) else None
+        alb = M.get("albedo") if isinstance(M, dict) else None
+        if _truthy(alb):
+            return tuple(_clamp01(_num_or_zero(alb[k] if k < len(alb) else None)) for k in range(3))
+    if _is_finite_number(m):
+        return LEGACY_COLORS.get(int(m), FALLBACK_COLOR)
+    return FALLBACK_COLOR
+
+
+def _geom_list(scene, key):
+    v = scene.get(key)
+    if _truthy(v):
+        return v
+    g = scene.get("geometry")
+    v = g.get(key) if isinstance(g, dict) else None
+    return v if _truthy(v) else []
+
+
+def build_geometry(scene):
+    """Scene object -> (vbo float32[V, 9] = pos3|nrm3|col3, idx uint32[T*3]) as raster.js:148-257.
+
+    Ingests `tris`, `planes`, `spheres` (top level or under `geometry`); `quads` are ignored exactly
+    as the reference ignores them.  Returns empty arrays for a null scene.
+    """
+    if not scene:
+        return np.zeros((0, 9), dtype=np.float32), np.zeros(0, dtype=np.uint32)
+    pos, nrm, col, idx = [], [], [], []
+
+    def push_tri(a, b, c, color):
+        U = (b[0] - a[0], b[1] - a[1], b[2] - a[2])
+        V = (c[0] - a[0], c[1] - a[1], c[2] - a[2])
+        N = _cross(U, V)
+        L = _hypot3(*N)
+        N = (N[0] / L, N[1] / L, N[2] / L) if L > 1e-8 else (0.0, 1.0, 0.0)
+        base = len(pos)
+        pos.extend([tuple(a[:3]), tuple(b[:3]), tuple(c[:3])])
+        nrm.extend([N, N, N])
+        col.extend([tuple(color[:3])] * 3)
+        idx.extend([base, base + 1, base + 2])
+
+    for t in _geom_list(scene, "tris"):
+        push_tri(_or(t.get("a"), (0, 0, 0)), _or(t.get("b"), (1, 0, 0)), _or(t.get("c"), (0, 1, 0)),
+                 resolve_color(scene, t.get("mat"), t.get("m")))
+
+    for p in _geom_list(scene, "planes"):
+        n = _or(p.get("n"), (0, 1, 0))
+        d = p.get("d") if _is_finite_number(p.get("d")) else 0
+        color = resolve_color(scene, p.get("mat"), p.get("m"))
+        N = _normalize((n[0], n[1], n[2]))
+        P0 = (-d * N[0], -d * N[1], -d * N[2])
+        tmp = (0, 1, 0) if abs(N[1]) < 0.99 else (1, 0, 0)
+        b1 = _normalize(_cross(N, tmp))
+        b2 = _normalize(_cross(N, b1))
+        S = PLANE_HALF_SIZE
+
+        def corner(s1, s2):
+            return tuple(P0[k] + (s1 * S * b1[k] + s2 * S * b2[k]) for k in range(3))
+
+        # (-S*b1 - S*b2) etc.: the reference writes "-S*b1.x - S*b2.x", i.e. (s1*S*b1) + (s2*S*b2)
+        v0, v1, v2, v3 = corner(-1, -1), corner(1, -1), corner(1, 1), corner(-1, 1)
+        push_tri(v0, v1, v2, color)
+        push_tri(v0, v2, v3, color)
+
+    for s in _geom_list(scene, "spheres"):
+        c = _or(s.get("p"), (0, 0, 0))
+        r = s.get("r") if _is_finite_number(s.get("r")) else 1
+        color = resolve_color(scene, s.get("mat"), s.get("m"))
+        base_vert = len(pos)
+        for iy in range(SPHERE_LAT + 1):
+            phi = (iy / SPHERE_LAT) * math.pi
+            sp, cp = math.sin(phi), math.cos(phi)
+            for ix in range(SPHERE_LON + 1):
+                th = (ix / SPHERE_LON) * 2 * math.pi
+                st, ct = math.sin(th), math.cos(th)
+                nx, ny, nz = ct * sp, cp, st * sp
+                pos.append((c[0] + r * nx, c[1] + r * ny, c[2] + r * nz))
+                nrm.append((nx, ny, nz))
+                col.append(tuple(color[:3]))
+        for iy in range(SPHERE_LAT):
+            for ix in range(SPHERE_LON):
+                i0 = base_vert + iy * (SPHERE_LON + 1) + ix
+                i1, i2 = i0 + 1, i0 + (SPHERE_LON + 1)
+                i3 = i2 + 1
+                idx.extend([i0, i2, i1, i1, i2, i3])
+
+    V = len(pos)
+    vbo = np.zeros((V, 9), dtype=np.float32)
+    if V:
+        vbo[:, 0:3] = np.asarray(pos, dtype=np.float64)
+        vbo[:, 3:6] = np.asarray(nrm, dtype=np.float64)
+        vbo[:, 6:9] = np.asarray(col, dtype=np.float64)
+    return vbo, np.asarray(idx, dtype=np.uint32)
+
+
+def mesh_to_vbo(positions, indices, colors=None):
+    """Typed-array fast path: indexed mesh (float positions [V,3], uint32 indices [T,3], optional
+    per-triangle albedo [T,3]) -> the reference's unshared flat-shaded layout, vectorised.
+
+    Equivalent to pushing every triangle through raster.js:159-169 (flat normal
+    normalize(cross(b-a, c-a)) in binary64, (0,1,0) when |N| <= 1e-8), colour default
+    (0.8, 0.8, 0.8).
+    """
+    P = np.asarray(positions, dtype=np.float64).reshape(-1, 3)
+    I = np.asarray(indices, dtype=np.int64).reshape(-1, 3)
+    a, b, c = P[I[:, 0]], P[I[:, 1]], P[I[:, 2]]
+    U, V = b - a, c - a
+    N = np.stack([U[:, 1] * V[:, 2] - U[:, 2] * V[:, 1],
+                  U[:, 2] * V[:, 0] - U[:, 0] * V[:, 2],
+                  U[:, 0] * V[:, 1] - U[:, 1] * V[:, 0]], axis=1)
+    L = np.sqrt(N[:, 0] ** 2 + N[:, 1] ** 2 + N[:, 2] ** 2)
+    ok = L > 1e-8
+    N = np.where(ok[:, None], N / np.where(ok, L, 1.0)[:, None], np.array([0.0, 1.0, 0.0]))
+    T = I.shape[0]
+    if colors is None:
+        C = np.broadcast_to(np.asarray(FALLBACK_COLOR), (T, 3))
+    else:
+        C = np.asarray(colors, dtype=np.float64).reshape(T, 3)
+    vbo = np.zeros((T, 3, 9), dtype=np.float32)
+    vbo[:, 0, 0:3], vbo[:, 1, 0:3], vbo[:, 2, 0:3] = a, b, c
+    vbo[:, :, 3:6] = N[:, None, :]
+    vbo[:, :, 6:9] = C[:, None, :]
+    return vbo.reshape(T * 3, 9), np.arange(T * 3, dtype=np.uint32)

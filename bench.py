@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Benchmark of the 3D -> ASCII raster path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A step is one frame of the hot path (clear, vertex transform + raster + z-resolve, shade, ASCII) over
+the synthetic workload "1M random triangles, 1920x1080 cells" with mesh, camera and lights already
+resident in HBM.  With N > 1 (one process per GPU, launched by torch.distributed.run) the frame is
+split into N horizontal strips, each rank renders its strip from its own replica of the mesh and the
+ASCII strips are combined by one RCCL all-gather per frame (total work fixed: "strong" scaling).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E peak
+N_TRIS = 1_000_000
+COLS, ROWS = 1920, 1080
+
+
+def cpu_baseline(ar, sc, budget_s=10.0):
+    """The CPU oracle (a scalar port; the reference has no CPU rasterizer) timed on this host."""
+    from oracle import oracle as orc
+    orc.build()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        rgba, _d, _i = orc.render(sc["vbo"], sc["idx"], sc["proj"], sc["view"], sc["lights"], sc["cols"], sc["rows"], want_ids=False)
+        orc.quantize(rgba, sc["cols"], sc["rows"], ar.scenes.DEFAULT_RAMP, 1, 2, 12)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s and n >= 3:
+            break
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d full frames of the same workload (%d tris, %dx%d), single thread, host has %d logical cpus"
+                      % (n, sc["idx"].size // 3, sc["cols"], sc["rows"], os.cpu_count() or 0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--tris", type=int, default=N_TRIS)
+    ap.add_argument("--cols", type=int, default=COLS)
+    ap.add_argument("--rows", type=int, default=ROWS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    ar = importlib.import_module("ascii-renderer_amd")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    mg = importlib.import_module("ascii-renderer_amd.multigpu")
+    sc = ar.scenes.random_scene(args.tris, args.cols, args.rows)
+    R = ar.Renderer(local_rank)
+    ar.scenes.upload(R, sc)
+    row0, row1 = mg.strip_bounds(args.rows, world, rank)
+    if world > 1:
+        R.set_strip(row0, row1)
+        gathered = torch.empty((args.rows, args.cols), dtype=torch.uint8, device="cuda")
+    R.render_async(args.cols, args.rows)
+    R.sync()
+    if world > 1:
+        local = mg.device_strip_tensor(R, args.cols, args.rows, row0, row1)
+
+    def step():
+        R.render_async(args.cols, args.rows)
+        if world > 1:
+            R.sync()                                   # the strip must be complete before RCCL reads it
+            mg.all_gather_strips(local, gathered)
+
+    def fence():
+        R.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    fps = args.steps / dt
+
+    # per-kernel durations (HIP events on the renderer's stream) over a second pass of the same steps
+    R.set_profiling(True)
+    R.kernel_stats()
+    for _ in range(args.steps):
+        R.render_async(args.cols, args.rows)
+    stats = R.kernel_stats()
+    R.set_profiling(False)
+    counters = R.frame_counters()
+
+    if rank == 0:
+        cells = args.cols * (row1 - row0)
+        per_launch_bytes = {                             # algorithmic bytes one launch must move
+            "k_raster": args.tris * 120,                 # 3 x 36 B vertices + 12 B indices per triangle
+            "k_shade": cells * 9,                        # RGBA8 + depth f32 + ASCII per cell
+            "k_clear": cells * 8, "k_ascii": cells * 5, "k_raster_medium": 0, "k_raster_large": 0,
+        }
+        kern = {k: {"launches": n, "avg_us": 1e3 * ms / n} for k, (n, ms) in stats.items() if n}
+        dom = max(kern, key=lambda k: kern[k]["avg_us"])
+        dom_s = kern[dom]["avg_us"] * 1e-6
+        achieved = per_launch_bytes.get(dom, 0) / dom_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh).get(dom)
+        line = {
+            "metric": "frames/sec at 1920x1080 cell grid, 1M tris", "value": fps, "unit": "frames/s",
+            "mtri_per_s": fps * args.tris / 1e6,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32+f64",
+            "data": "synthetic",
+            "config": {"workload": "random mesh mulberry32(0xA5C11), %d tris, %dx%d cells, camera at origin, default lights, "
+                                   "modal smoothing on" % (args.tris, args.cols, args.rows),
+                       "partition": "1 GPU" if world == 1 else "%d row strips + RCCL all-gather of ASCII" % world,
+                       "algorithmic_bytes_per_frame": ar.scenes.algorithmic_bytes(args.tris, args.cols, args.rows),
+                       "frame_hbm_frac": ar.scenes.algorithmic_bytes(args.tris, args.cols, args.rows) * fps / 1e9 / HBM_PEAK_GBPS,
+                       "queued_records": counters},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic},
+            "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(ar, sc)
+        print(json.dumps(line), flush=True)
+    R.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

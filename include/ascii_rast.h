@@ -1,0 +1,108 @@
+/*
+ * ascii_rast.h - C ABI of the MI355X (gfx950) 3D -> ASCII rasterizer library (libascii_rast.so).
+ *
+ * This is the drop-in boundary for the reference's raster backend + ASCII stage.  Each entry point
+ * names the reference interface it replaces (paths relative to the reference tree).  Plain pointers
+ * and sizes only; every pointer argument is HOST memory unless its name starts with d_.
+ * All functions returning int return 0 on success and a negative AR_E_* code on failure; the message
+ * is available from ar_last_error().  One context is used from one host thread at a time.
+ */
+#ifndef ASCII_RAST_H
+#define ASCII_RAST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AR_MAX_POINT_LIGHTS 8   /* js/render/backends/raster_shader.js:5 */
+#define AR_MAX_RAMP 256
+
+#define AR_E_ARG     (-1)  /* invalid argument */
+#define AR_E_HIP     (-2)  /* a HIP runtime call failed */
+#define AR_E_STATE   (-3)  /* call made in the wrong state (e.g. read before any render) */
+#define AR_E_NOMEM   (-4)
+
+typedef struct ar_ctx ar_ctx;
+
+/* Creates a renderer bound to one GPU and one HIP stream of its own.
+ * Replaces: RasterBackend constructor + _ensureGL (js/render/backends/raster.js:52-103), i.e. what
+ * the router's factory() call instantiates (js/gpu_renderer.js:74).  NULL on failure
+ * (ar_last_error(NULL) tells why). */
+ar_ctx *ar_create(int device_id);
+
+/* Replaces: RasterBackend.dispose (raster.js:116-127).  NULL is accepted. */
+void ar_destroy(ar_ctx *ctx);
+
+/* Message of the most recent failure on ctx (or of the last failed ar_create when ctx is NULL). */
+const char *ar_last_error(ar_ctx *ctx);
+
+/* Uploads the geometry: vbo9 = n_verts x (pos3, nrm3, col3) binary32, idx = n_tris x 3 u32 - the
+ * exact buffers RasterBackend._rebuildGeometry hands to gl.bufferData (raster.js:222-251).
+ * n_tris == 0 clears the geometry (render then leaves the outputs untouched, raster.js:274).
+ * Indices >= n_verts make their triangle invisible. */
+int ar_set_mesh(ar_ctx *ctx, const float *vbo9, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris);
+
+/* Column-major projection and view matrices, as RasterBackend.render uploads to uProj / uView
+ * (raster.js:296-304). */
+int ar_set_camera(ar_ctx *ctx, const float proj[16], const float view[16]);
+
+/* Light uniforms as packed by raster.js:307-342: uAmbient, uLightDir, uLightColor, uPLCount and the
+ * first n_pl entries of uPLPos / uPLCol (n_pl <= AR_MAX_POINT_LIGHTS, 3 floats each). */
+int ar_set_lights(ar_ctx *ctx, const float amb[3], const float dir[3], const float dircol[3],
+                  int n_pl, const float *plpos, const float *plcol);
+
+/* ASCII stage parameters: the ramp string baked into the shader (js/ascii_pass_shader.js:8-16,
+ * js/ascii_pass.js:142) and the uModeOn / uModeRadius / uModeThresh uniforms (ascii_pass.js:294-299).
+ * Defaults: ramp "@%#*+=-:. ", mode on, radius 2, threshold 12 (js/config.js:15,26-34). */
+int ar_set_ascii(ar_ctx *ctx, const uint8_t *ramp, int ramp_len, int mode_on, int mode_radius, int mode_thresh);
+
+/* Restricts rendering to output rows [row0, row1) of the frame (screen-strip partition for multi-GPU
+ * runs; no counterpart in the single-GPU reference).  row0 = 0, row1 = 0 means the whole frame.
+ * Rows outside the strip are left untouched in every output buffer. */
+int ar_set_strip(ar_ctx *ctx, int row0, int row1);
+
+/* Renders one frame at cols x rows cells and blocks until done.
+ * Replaces: RasterBackend.render from the clear to readPixels + flipAndCopy (raster.js:276-361,
+ * js/render/gl/context.js:117-124) plus the index half of AsciiPass.draw (js/ascii_pass.js:257-302,
+ * js/ascii_pass_shader.js:140-188).  Outputs (each may be NULL; all row 0 = top of the image):
+ *   rgba  cols*rows*4 bytes, alpha 255;  depth cols*rows binary32 window depth, 1.0 = background;
+ *   ascii cols*rows ASCII codes (== glyph-atlas tile indices, ascii_pass_shader.js:190-199).
+ * With no geometry the call succeeds and leaves the output buffers untouched. */
+int ar_render(ar_ctx *ctx, int cols, int rows, uint8_t *rgba, float *depth, uint8_t *ascii);
+
+/* The same frame without the device->host copies: enqueue on the context's stream / wait for it /
+ * copy out what is wanted afterwards (ids = per cell 2*triangle + sub-triangle, 0xFFFFFFFF background).
+ * Lets a caller keep the outputs resident in HBM (benchmarks, multi-GPU gathers). */
+int ar_render_async(ar_ctx *ctx, int cols, int rows);
+int ar_sync(ar_ctx *ctx);
+int ar_read(ar_ctx *ctx, uint8_t *rgba, float *depth, uint8_t *ascii, uint32_t *ids);
+
+/* Device addresses of the current output buffers (valid until the grid size changes or the context
+ * is destroyed): which = 0 rgba, 1 depth, 2 ascii.  NULL before the first render. */
+void *ar_device_buffer(ar_ctx *ctx, int which);
+
+/* The HIP stream (hipStream_t) the context launches on. */
+void *ar_stream(ar_ctx *ctx);
+
+/* RGBA8 grid -> ASCII codes with the context's ASCII parameters; alpha 2..254 is a literal code.
+ * Replaces: AsciiPass.drawFromBuffer = blit + draw, index half (ascii_pass.js:238-302) and its CPU
+ * twins compositeAndQuantize (js/renderer.js:59-72) / _computeRowString (js/text_overlay.js:128-148). */
+int ar_quantize(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *ascii);
+
+/* Per-kernel timing with HIP events on the context's stream.  While on, every launch is bracketed by
+ * events; ar_kernel_stats drains them (blocking) and reports, per kernel slot, the number of launches
+ * and the summed duration in milliseconds since the last call.  names receives static strings. */
+#define AR_N_KERNELS 8
+int ar_set_profiling(ar_ctx *ctx, int on);
+int ar_kernel_stats(ar_ctx *ctx, const char *names[AR_N_KERNELS], uint32_t launches[AR_N_KERNELS], float total_ms[AR_N_KERNELS]);
+
+/* Counters of the last rendered frame: [0] triangles submitted, [1] records queued for the
+ * medium-triangle pass, [2] records queued for the large-triangle pass, [3] reserved. */
+int ar_frame_counters(ar_ctx *ctx, uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASCII_RAST_H */

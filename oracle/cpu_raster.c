@@ -1,0 +1,353 @@
+/*
+ * cpu_raster.c - CPU ORACLE for the 3D -> ASCII raster path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is a checker: tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg are the
+ * only callers.  Nothing in the product path (the HIP library, the N-API addon, the JS host) links,
+ * loads or calls it.
+ *
+ * It restates, as plain scalar C, what the reference does on one frame of its raster backend:
+ *
+ *   stage                                   reference                                  pinned by
+ *   --------------------------------------  -----------------------------------------  ----------------
+ *   vertex shader  clip = P*V*[p,1]         js/render/backends/raster_shader.js:17-22  (WebGL; unpinned)
+ *   clip / cull / raster / depth test       WebGL fixed function configured by         (WebGL; unpinned)
+ *                                           js/render/backends/raster.js:100-102,
+ *                                           276-279,355; target js/render/gl/context.js:88-115
+ *   fragment shader (Lambert + <=8 points)  raster_shader.js:42-62                     (WebGL; unpinned)
+ *   readPixels + row flip                   raster.js:358-361, context.js:117-124      (WebGL; unpinned)
+ *   luminance -> ramp -> ASCII code         js/renderer.js:59-72,                      golden vectors
+ *                                           js/text_overlay.js:137-145,                tests/golden/
+ *                                           js/ascii_pass_shader.js:12-16,62-68        ref_quantize.json
+ *   alpha override (2..254 = literal code)  ascii_pass_shader.js:153-162               golden vectors
+ *   modal (majority) smoothing              ascii_pass_shader.js:77-138,169-185        (GLSL; unpinned)
+ *
+ * PARITY UNPINNED for the rows marked "WebGL"/"GLSL": that arithmetic runs inside the browser's WebGL
+ * implementation, which is not part of the reference tree and has no golden outputs there.  For those
+ * rows this file is the definition: it follows the OpenGL ES rules the reference's GL state selects
+ * and fixes every choice the GL specification leaves open (listed below).  The quantizer rows are
+ * pinned against outputs of the reference's own compositeAndQuantize.
+ *
+ * Numeric contract (every implementation that claims parity follows exactly this):
+ *   - IEEE-754 binary32/binary64, round-to-nearest-even, denormals kept, NO fused multiply-add,
+ *     correctly rounded / and sqrt.  Expressions are evaluated left to right as parenthesised here.
+ *   - PV = P*V in binary32 (column-major, k = 0..3 left to right); clip = PV*[x,y,z,1].
+ *   - near plane: a vertex is inside when z_c + w_c >= 0.  Triangles with 1 or 2 vertices outside are
+ *     clipped against that plane only (new vertex = I + (O - I) * (dI / (dI - dO)), always computed
+ *     from the inside vertex I towards the outside vertex O, for clip coordinates and all varyings),
+ *     giving 1 or 2 sub-triangles in the original winding.  No x/y/far geometric clipping: x/y are
+ *     handled by scanning only cells of the viewport, far by the depth test against the clear value.
+ *   - pixel-homogeneous vertex (X,Y,W) = ((x_c + w_c)*cols/2, (y_c + w_c)*rows/2, w_c) in binary32,
+ *     GL window orientation (y up).  Edge functions are the cross products of those vectors taken in
+ *     binary64 (a,b,c) and evaluated in binary64 at cell centres (i+0.5, j+0.5): E = (a*px + b*py) + c.
+ *     det = (X0*a0 + Y0*b0) + W0*c0 in binary64; det <= 0 is culled (back face or zero area).
+ *     A cell is covered when every E_k > 0, or E_k == 0 on an edge with a_k > 0 or (a_k == 0 and
+ *     b_k > 0) - a top-left style rule that gives exactly one owner on a shared edge because the
+ *     neighbour evaluates the exact negation.
+ *   - f_k = (float)E_k.  Depth (screen-linear, as GL requires) zn = ((f0*z0 + f1*z1) + f2*z2) /
+ *     ((f0*W0 + f1*W1) + f2*W2), zw = zn*0.5 + 0.5, kept only when 0 <= zw < 1; test LESS against a
+ *     buffer cleared to 1.0, stored as binary32 (the reference target is DEPTH_COMPONENT16; binary32
+ *     is this build's documented deviation).  Equal depth: the earlier triangle wins.
+ *   - varyings are perspective-correct: b_k = f_k * (1 / ((f0 + f1) + f2)); v = (b0*v0 + b1*v1) + b2*v2.
+ *   - fragment shader in binary32 as written in shade(); colour byte = floor(clamp(c,0,1)*255 + 0.5),
+ *     alpha 255; clear colour (0,0,0,255).
+ *   - output row 0 is the TOP image row (the reference flips after readPixels).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_MAX_POINT_LIGHTS 8 /* raster_shader.js:5 */
+
+typedef struct {
+    float c[4];   /* clip x,y,z,w */
+    float v[9];   /* varyings: world pos, normal, colour (raster_shader.js:18-20) */
+} orc_vert;
+
+typedef struct {
+    float amb[3], ldir[3], lcol[3];
+    int n_pl;
+    float plpos[3 * ORC_MAX_POINT_LIGHTS], plcol[3 * ORC_MAX_POINT_LIGHTS];
+} orc_lights;
+
+/* PV = P*V, column-major 4x4, binary32.  (GLSL evaluates uProj * uView * v as (uProj*uView)*v.) */
+void orc_matmul_pv(const float *P, const float *V, float *PV)
+{
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++)
+            PV[c * 4 + r] = ((P[0 * 4 + r] * V[c * 4 + 0] + P[1 * 4 + r] * V[c * 4 + 1]) +
+                             P[2 * 4 + r] * V[c * 4 + 2]) + P[3 * 4 + r] * V[c * 4 + 3];
+}
+
+/* raster_shader.js:17-22: gl_Position = uProj * uView * vec4(a_pos, 1.0); varyings copied. */
+static void vertex_shader(const float *PV, const float *vtx9, orc_vert *o)
+{
+    const float x = vtx9[0], y = vtx9[1], z = vtx9[2];
+    for (int r = 0; r < 4; r++)
+        o->c[r] = ((PV[0 * 4 + r] * x + PV[1 * 4 + r] * y) + PV[2 * 4 + r] * z) + PV[3 * 4 + r];
+    for (int k = 0; k < 9; k++) o->v[k] = vtx9[k];
+}
+
+/* new vertex on the near plane, always from the inside vertex I towards the outside vertex O */
+static void clip_vertex(const orc_vert *I, float dI, const orc_vert *O, float dO, orc_vert *out)
+{
+    const float t = dI / (dI - dO);
+    for (int k = 0; k < 4; k++) out->c[k] = I->c[k] + (O->c[k] - I->c[k]) * t;
+    for (int k = 0; k < 9; k++) out->v[k] = I->v[k] + (O->v[k] - I->v[k]) * t;
+}
+
+/* Near-plane clip of one triangle; returns the number of sub-triangles (0, 1 or 2). */
+static int clip_near(const orc_vert in[3], orc_vert out[2][3])
+{
+    float d[3];
+    int inside[3], n_in = 0;
+    for (int k = 0; k < 3; k++) {
+        d[k] = in[k].c[2] + in[k].c[3];
+        inside[k] = d[k] >= 0.0f;
+        n_in += inside[k];
+    }
+    if (n_in == 0) return 0;
+    if (n_in == 3) { memcpy(out[0], in, 3 * sizeof(orc_vert)); return 1; }
+    if (n_in == 1) {
+        int a = inside[0] ? 0 : (inside[1] ? 1 : 2), b = (a + 1) % 3, c = (a + 2) % 3;
+        out[0][0] = in[a];
+        clip_vertex(&in[a], d[a], &in[b], d[b], &out[0][1]);
+        clip_vertex(&in[a], d[a], &in[c], d[c], &out[0][2]);
+        return 1;
+    }
+    /* two inside: a is the outside vertex, (a,b,c) cyclic */
+    {
+        int a = !inside[0] ? 0 : (!inside[1] ? 1 : 2), b = (a + 1) % 3, c = (a + 2) % 3;
+        orc_vert pab, pca;
+        clip_vertex(&in[b], d[b], &in[a], d[a], &pab);
+        clip_vertex(&in[c], d[c], &in[a], d[a], &pca);
+        out[0][0] = pab; out[0][1] = in[b]; out[0][2] = in[c];
+        out[1][0] = pab; out[1][1] = in[c]; out[1][2] = pca;
+        return 2;
+    }
+}
+
+/* raster_shader.js:42-62 in binary32; returns RGBA8 with alpha 255. */
+static void shade(const float v[9], const orc_lights *L, uint8_t rgba[4])
+{
+    const float *pos = v, *nrm = v + 3, *vc = v + 6;
+    const float len2 = (nrm[0] * nrm[0] + nrm[1] * nrm[1]) + nrm[2] * nrm[2];
+    const float inv = (len2 > 0.0f) ? 1.0f / sqrtf(len2) : 0.0f;       /* N = normalize(v_nrm) */
+    const float N[3] = { nrm[0] * inv, nrm[1] * inv, nrm[2] * inv };
+    float col[3];
+    for (int k = 0; k < 3; k++) col[k] = vc[k] * L->amb[k];             /* col = v_col * uAmbient */
+    const float ndl = fmaxf((N[0] * (-L->ldir[0]) + N[1] * (-L->ldir[1])) + N[2] * (-L->ldir[2]), 0.0f);
+    for (int k = 0; k < 3; k++) col[k] = col[k] + (vc[k] * L->lcol[k]) * ndl;
+    for (int i = 0; i < ORC_MAX_POINT_LIGHTS; i++) {
+        if (i >= L->n_pl) break;
+        const float lv[3] = { L->plpos[3 * i] - pos[0], L->plpos[3 * i + 1] - pos[1], L->plpos[3 * i + 2] - pos[2] };
+        const float d2 = fmaxf((lv[0] * lv[0] + lv[1] * lv[1]) + lv[2] * lv[2], 1e-4f);
+        const float il = 1.0f / sqrtf(d2);                              /* inversesqrt */
+        const float Ld[3] = { lv[0] * il, lv[1] * il, lv[2] * il };
+        const float ndlp = fmaxf((N[0] * Ld[0] + N[1] * Ld[1]) + N[2] * Ld[2], 0.0f);
+        const float atten = 1.0f / (1.0f + d2 * 0.05f);
+        const float w = ndlp * atten;
+        for (int k = 0; k < 3; k++) col[k] = col[k] + (vc[k] * L->plcol[3 * i + k]) * w;
+    }
+    for (int k = 0; k < 3; k++) {
+        const float c = fminf(fmaxf(col[k], 0.0f), 1.0f);
+        rgba[k] = (uint8_t)(int)floorf(c * 255.0f + 0.5f);
+    }
+    rgba[3] = 255;
+}
+
+static int edge_inside(double E, double a, double b)
+{
+    return E > 0.0 || (E == 0.0 && (a > 0.0 || (a == 0.0 && b > 0.0)));
+}
+
+/* Rasterize one (sub-)triangle into the bottom-up work buffers. */
+static void raster_tri(const orc_vert t[3], uint32_t tri_id, const orc_lights *L, int cols, int rows,
+                       uint8_t *rgba, float *depth, uint32_t *ids)
+{
+    float X[3], Y[3], W[3], Z[3];
+    const float hw = (float)cols * 0.5f, hh = (float)rows * 0.5f;
+    for (int k = 0; k < 3; k++) {
+        for (int q = 0; q < 4; q++) if (!isfinite(t[k].c[q])) return;
+        if (!(t[k].c[3] > 0.0f)) return;
+        W[k] = t[k].c[3];
+        Z[k] = t[k].c[2];
+        X[k] = (t[k].c[0] + W[k]) * hw;
+        Y[k] = (t[k].c[1] + W[k]) * hh;
+    }
+    double a[3], b[3], c[3];
+    for (int k = 0; k < 3; k++) {                   /* e_k = v_{k+1} x v_{k+2} */
+        const int p = (k + 1) % 3, q = (k + 2) % 3;
+        a[k] = (double)Y[p] * (double)W[q] - (double)Y[q] * (double)W[p];
+        b[k] = (double)X[q] * (double)W[p] - (double)X[p] * (double)W[q];
+        c[k] = (double)X[p] * (double)Y[q] - (double)X[q] * (double)Y[p];
+    }
+    const double det = ((double)X[0] * a[0] + (double)Y[0] * b[0]) + (double)W[0] * c[0];
+    if (!(det > 0.0)) return;                       /* CULL_FACE BACK, CCW front; zero area */
+
+    /* conservative cell range: any superset of the covered cells gives the same image */
+    float minx = X[0] / W[0], maxx = minx, miny = Y[0] / W[0], maxy = miny;
+    for (int k = 1; k < 3; k++) {
+        const float sx = X[k] / W[k], sy = Y[k] / W[k];
+        minx = fminf(minx, sx); maxx = fmaxf(maxx, sx);
+        miny = fminf(miny, sy); maxy = fmaxf(maxy, sy);
+    }
+    const float lox = ceilf(fmaxf(minx - 0.50390625f, 0.0f)), hix = floorf(fminf(maxx - 0.49609375f, (float)(cols - 1)));
+    const float loy = ceilf(fmaxf(miny - 0.50390625f, 0.0f)), hiy = floorf(fminf(maxy - 0.49609375f, (float)(rows - 1)));
+    if (!(lox <= hix) || !(loy <= hiy)) return;
+    const int i0 = (int)lox, i1 = (int)hix, j0 = (int)loy, j1 = (int)hiy;
+
+    for (int j = j0; j <= j1; j++) {
+        const double py = (double)j + 0.5;
+        for (int i = i0; i <= i1; i++) {
+            const double px = (double)i + 0.5;
+            const double E0 = (a[0] * px + b[0] * py) + c[0];
+            const double E1 = (a[1] * px + b[1] * py) + c[1];
+            const double E2 = (a[2] * px + b[2] * py) + c[2];
+            if (!edge_inside(E0, a[0], b[0]) || !edge_inside(E1, a[1], b[1]) || !edge_inside(E2, a[2], b[2]))
+                continue;
+            const float f0 = (float)E0, f1 = (float)E1, f2 = (float)E2;
+            const float den = (f0 * W[0] + f1 * W[1]) + f2 * W[2];
+            const float num = (f0 * Z[0] + f1 * Z[1]) + f2 * Z[2];
+            const float zn = num / den;
+            const float zw = zn * 0.5f + 0.5f;
+            if (!(zw >= 0.0f) || !(zw < 1.0f)) continue;
+            const size_t cell = (size_t)j * cols + i;
+            if (!(zw < depth[cell])) continue;      /* depthFunc LESS */
+            depth[cell] = zw;
+            if (ids) ids[cell] = tri_id;
+            const float rS = 1.0f / ((f0 + f1) + f2);
+            const float b0 = f0 * rS, b1 = f1 * rS, b2 = f2 * rS;
+            float v[9];
+            for (int q = 0; q < 9; q++) v[q] = (b0 * t[0].v[q] + b1 * t[1].v[q]) + b2 * t[2].v[q];
+            shade(v, L, rgba + cell * 4);
+        }
+    }
+}
+
+/*
+ * Render one frame.  vbo9: n_verts x (pos3, nrm3, col3) binary32 (raster.js:222-236); idx: n_tris x 3
+ * u32 (raster.js:249).  proj/view: column-major binary32 as uploaded by raster.js:303-304.  Lights as
+ * packed by raster.js:307-342.  Outputs are TOP-DOWN (row 0 = top): rgba_out cols*rows*4, depth_out
+ * cols*rows (1.0 = background), ids_out cols*rows (0xFFFFFFFF = background); any may be NULL.
+ * Triangles naming a vertex >= n_verts are skipped.  Returns 0, or -1 on bad arguments.
+ */
+int orc_render(const float *vbo9, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris,
+               const float *proj, const float *view,
+               const float *amb, const float *ldir, const float *lcol,
+               int n_pl, const float *plpos, const float *plcol,
+               int cols, int rows, uint8_t *rgba_out, float *depth_out, uint32_t *ids_out)
+{
+    if (cols <= 0 || rows <= 0 || n_pl < 0 || n_pl > ORC_MAX_POINT_LIGHTS) return -1;
+    const size_t n = (size_t)cols * rows;
+    uint8_t *rgba = (uint8_t *)malloc(n * 4);
+    float *depth = (float *)malloc(n * sizeof(float));
+    uint32_t *ids = ids_out ? (uint32_t *)malloc(n * sizeof(uint32_t)) : NULL;
+    if (!rgba || !depth || (ids_out && !ids)) { free(rgba); free(depth); free(ids); return -1; }
+    for (size_t p = 0; p < n; p++) {                /* clearColor(0,0,0,1), clearDepth 1.0 */
+        rgba[4 * p] = rgba[4 * p + 1] = rgba[4 * p + 2] = 0; rgba[4 * p + 3] = 255;
+        depth[p] = 1.0f;
+        if (ids) ids[p] = 0xFFFFFFFFu;
+    }
+    orc_lights L;
+    memset(&L, 0, sizeof L);
+    for (int k = 0; k < 3; k++) { L.amb[k] = amb[k]; L.ldir[k] = ldir[k]; L.lcol[k] = lcol[k]; }
+    L.n_pl = n_pl;
+    for (int k = 0; k < 3 * n_pl; k++) { L.plpos[k] = plpos[k]; L.plcol[k] = plcol[k]; }
+
+    float PV[16];
+    orc_matmul_pv(proj, view, PV);
+    for (uint32_t t = 0; t < n_tris; t++) {
+        const uint32_t i0 = idx[3 * t], i1 = idx[3 * t + 1], i2 = idx[3 * t + 2];
+        if (i0 >= n_verts || i1 >= n_verts || i2 >= n_verts) continue;
+        orc_vert in[3], sub[2][3];
+        vertex_shader(PV, vbo9 + (size_t)i0 * 9, &in[0]);
+        vertex_shader(PV, vbo9 + (size_t)i1 * 9, &in[1]);
+        vertex_shader(PV, vbo9 + (size_t)i2 * 9, &in[2]);
+        const int ns = clip_near(in, sub);
+        for (int s = 0; s < ns; s++) raster_tri(sub[s], t, &L, cols, rows, rgba, depth, ids);
+    }
+    for (int r = 0; r < rows; r++) {                /* flipAndCopy: output row r = GL row rows-1-r */
+        const size_t src = (size_t)(rows - 1 - r) * cols, dst = (size_t)r * cols;
+        if (rgba_out) memcpy(rgba_out + dst * 4, rgba + src * 4, (size_t)cols * 4);
+        if (depth_out) memcpy(depth_out + dst, depth + src, (size_t)cols * sizeof(float));
+        if (ids_out) memcpy(ids_out + dst, ids + src, (size_t)cols * sizeof(uint32_t));
+    }
+    free(rgba); free(depth); free(ids);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * ASCII stage.
+ * ramp index (js/renderer.js:67-70, text_overlay.js:142-143):
+ *     idx = clamp(round(((r+g+b)/3/255) * (L-1)), 0, L-1)
+ * evaluated here exactly as the reference does, in binary64 with Math.round = floor(x + 0.5).
+ * The product path uses the equivalent integer form floor((2*s*(L-1) + 765) / 1530); tests check both
+ * against the reference's recorded outputs.
+ * ---------------------------------------------------------------------------------------------- */
+static int ramp_index(int r, int g, int b, int ramp_len)
+{
+    const double intensity = (double)(r + g + b) / 3.0;
+    double idx = floor((intensity / 255.0) * (double)(ramp_len - 1) + 0.5);
+    if (idx < 0.0) idx = 0.0;
+    if (idx > (double)(ramp_len - 1)) idx = (double)(ramp_len - 1);
+    return (int)idx;
+}
+
+static int is_override(int a) { return a >= 2 && a <= 254; } /* ascii_pass_shader.js:98,155 */
+
+/*
+ * RGBA8 grid (row-major, as handed to AsciiPass.blit, js/ascii_pass.js:243-255) -> one ASCII code per
+ * cell.  mode_on / mode_radius / mode_thresh are the uniforms uModeOn / uModeRadius / uModeThresh
+ * (ascii_pass.js:294-299); radius is clamped to 1..3 as the shader does (ascii_pass_shader.js:173-175).
+ * Neighbour order dy outer, dx inner, coordinates clamped to the grid, centre skipped, override cells
+ * skipped (ascii_pass_shader.js:84-105).  Returns 0, or -1 on bad arguments.
+ */
+int orc_quantize(const uint8_t *rgba, int cols, int rows, const uint8_t *ramp, int ramp_len,
+                 int mode_on, int mode_radius, int mode_thresh, uint8_t *ascii_out)
+{
+    if (cols <= 0 || rows <= 0 || ramp_len <= 0) return -1;
+    const size_t n = (size_t)cols * rows;
+    int *base = (int *)malloc(n * sizeof(int));
+    if (!base) return -1;
+    for (size_t p = 0; p < n; p++)
+        base[p] = ramp_index(rgba[4 * p], rgba[4 * p + 1], rgba[4 * p + 2], ramp_len);
+    int radius = mode_radius;
+    if (radius < 1) radius = 1;
+    if (radius > 3) radius = 3;
+    for (int y = 0; y < rows; y++) {
+        for (int x = 0; x < cols; x++) {
+            const size_t p = (size_t)y * cols + x;
+            const int a = rgba[4 * p + 3];
+            if (is_override(a)) { ascii_out[p] = (uint8_t)a; continue; }
+            int final_idx = base[p];
+            if (mode_on == 1) {
+                int cand = -1, cnt = 0, votes = 0;
+                for (int pass = 0; pass < 2; pass++) {
+                    if (pass == 1 && cand < 0) break;
+                    for (int dy = -radius; dy <= radius; dy++) {
+                        for (int dx = -radius; dx <= radius; dx++) {
+                            if (dx == 0 && dy == 0) continue;
+                            int nx = x + dx, ny = y + dy;
+                            nx = nx < 0 ? 0 : (nx > cols - 1 ? cols - 1 : nx);
+                            ny = ny < 0 ? 0 : (ny > rows - 1 ? rows - 1 : ny);
+                            const size_t q = (size_t)ny * cols + nx;
+                            if (is_override(rgba[4 * q + 3])) continue;
+                            const int ni = base[q];
+                            if (pass == 0) {                    /* Boyer-Moore candidate */
+                                if (cnt == 0) { cand = ni; cnt = 1; }
+                                else if (ni == cand) cnt += 1;
+                                else cnt -= 1;
+                            } else if (ni == cand) votes += 1;  /* true vote count */
+                        }
+                    }
+                }
+                if (cand >= 0 && votes >= mode_thresh && cand != base[p]) final_idx = cand;
+            }
+            /* asciiFromRampIndex: out-of-range falls back to space (ascii_pass_shader.js:15) */
+            ascii_out[p] = (final_idx >= 0 && final_idx < ramp_len) ? ramp[final_idx] : 32;
+        }
+    }
+    free(base);
+    return 0;
+}

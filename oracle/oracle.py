@@ -1,0 +1,105 @@
+"""ctypes wrapper around the CPU oracle (oracle/cpu_raster.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by bench.py's
+cpu_baseline leg as the checker / reported baseline.  The product path never imports this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libcpu_raster.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile the C oracle with the recipe in oracle/Makefile."""
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "cpu_raster.c"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "libcpu_raster.so"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        fp = ctypes.POINTER(ctypes.c_float)
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        L.orc_matmul_pv.argtypes = [fp, fp, fp]
+        L.orc_matmul_pv.restype = None
+        L.orc_render.argtypes = [fp, ctypes.c_uint32, u32p, ctypes.c_uint32, fp, fp, fp, fp, fp,
+                                 ctypes.c_int, fp, fp, ctypes.c_int, ctypes.c_int, u8p, fp, u32p]
+        L.orc_render.restype = ctypes.c_int
+        L.orc_quantize.argtypes = [u8p, ctypes.c_int, ctypes.c_int, u8p, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, u8p]
+        L.orc_quantize.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def matmul_pv(proj, view):
+    p, pp = _f(proj)
+    v, vp = _f(view)
+    out = np.zeros(16, dtype=np.float32)
+    lib().orc_matmul_pv(pp, vp, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return out
+
+
+def render(vbo9, idx, proj, view, lights, cols, rows, want_ids=True):
+    """Returns (rgba[rows,cols,4] u8, depth[rows,cols] f32, ids[rows,cols] u32), all top-down.
+
+    lights: dict with 'ambient', 'dir', 'dir_color' (3 floats each) and 'pl_pos', 'pl_col'
+    (n x 3 each, n <= 8).
+    """
+    vbo, vbop = _f(np.asarray(vbo9).reshape(-1))
+    idx = np.ascontiguousarray(np.asarray(idx).reshape(-1), dtype=np.uint32)
+    n_verts = vbo.size // 9
+    n_tris = idx.size // 3
+    _p, pp = _f(proj)
+    _v, vp = _f(view)
+    _a, ap = _f(lights["ambient"])
+    _d, dp = _f(lights["dir"])
+    _c, cp = _f(lights["dir_color"])
+    plpos = np.asarray(lights.get("pl_pos", np.zeros((0, 3))), dtype=np.float32).reshape(-1, 3)
+    plcol = np.asarray(lights.get("pl_col", np.zeros((0, 3))), dtype=np.float32).reshape(-1, 3)
+    n_pl = plpos.shape[0]
+    _pp, ppp = _f(plpos if n_pl else np.zeros(3))
+    _pc, pcp = _f(plcol if n_pl else np.zeros(3))
+    rgba = np.zeros((rows, cols, 4), dtype=np.uint8)
+    depth = np.zeros((rows, cols), dtype=np.float32)
+    ids = np.zeros((rows, cols), dtype=np.uint32) if want_ids else None
+    rc = lib().orc_render(
+        vbop, n_verts, idx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n_tris, pp, vp, ap, dp, cp,
+        n_pl, ppp, pcp, cols, rows,
+        rgba.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+        depth.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+        ids.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)) if want_ids else None)
+    if rc != 0:
+        raise ValueError("orc_render rejected its arguments")
+    return rgba, depth, ids
+
+
+def quantize(rgba, cols, rows, ramp, mode_on=0, mode_radius=2, mode_thresh=12):
+    """RGBA8 grid -> uint8[rows, cols] ASCII codes (override / ramp / optional modal smoothing)."""
+    rgba = np.ascontiguousarray(np.asarray(rgba, dtype=np.uint8).reshape(-1))
+    if rgba.size != cols * rows * 4:
+        raise ValueError("rgba size does not match cols*rows*4")
+    ramp_b = np.frombuffer(ramp.encode("latin-1") if isinstance(ramp, str) else bytes(ramp), dtype=np.uint8).copy()
+    out = np.zeros((rows, cols), dtype=np.uint8)
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    rc = lib().orc_quantize(rgba.ctypes.data_as(u8p), cols, rows, ramp_b.ctypes.data_as(u8p), ramp_b.size,
+                            int(mode_on), int(mode_radius), int(mode_thresh), out.ctypes.data_as(u8p))
+    if rc != 0:
+        raise ValueError("orc_quantize rejected its arguments")
+    return out

@@ -1,0 +1,213 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  Bit-exact: RGBA8, ASCII codes,
+winning triangle ids and the binary32 depth bits must all be identical (the stated tolerance for
+depth is 1e-5; these tests hold it to 0)."""
+import base64
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def R(pkg):
+    r = pkg.Renderer(0)
+    yield r
+    r.close()
+
+
+def _check(pkg, oracle, R, sc, ramp="@%#*+=-:. ", mode=(True, 2, 12), label=""):
+    pkg.scenes.upload(R, sc, ramp, *mode)
+    out = R.render(sc["cols"], sc["rows"], want_ids=True)
+    rgba, depth, ids = oracle.render(sc["vbo"], sc["idx"], sc["proj"], sc["view"], sc["lights"], sc["cols"], sc["rows"])
+    ascii_ = oracle.quantize(rgba, sc["cols"], sc["rows"], ramp, int(mode[0]), mode[1], mode[2])
+    name = label or sc["name"]
+    assert np.array_equal(out["ids"], ids), "%s: %d cells differ in winner" % (name, np.count_nonzero(out["ids"] != ids))
+    assert np.array_equal(out["depth"].view(np.uint32), depth.view(np.uint32)), name
+    assert np.max(np.abs(out["depth"] - depth)) <= 1e-5
+    assert np.array_equal(out["rgba"], rgba), "%s: %d bytes differ" % (name, np.count_nonzero(out["rgba"] != rgba))
+    assert np.array_equal(out["ascii"], ascii_), name
+    return out, ids
+
+
+def test_c1_cube_orbit_60_frames(pkg, oracle, R):
+    covered = 0
+    for k in range(60):
+        sc = pkg.scenes.cube_scene(angle=2 * math.pi * k / 60)
+        out, ids = _check(pkg, oracle, R, sc, label="cube frame %d" % k)
+        covered += np.count_nonzero(ids != 0xFFFFFFFF)
+    assert covered > 60 * 100          # the cube is actually on screen
+
+
+def test_c2_icosphere_640x360(pkg, oracle, R):
+    sc = pkg.scenes.icosphere_scene()
+    out, ids = _check(pkg, oracle, R, sc)
+    assert np.unique(ids).size > 1000
+    assert len(set(out["ascii"].reshape(-1).tolist())) >= 5
+
+
+def test_c2_icosphere_point_lights_and_other_ramps(pkg, oracle, R):
+    sc = pkg.scenes.icosphere_scene(angle=1.9, point_lights=8)
+    _check(pkg, oracle, R, sc, ramp=" .:-=+*#%@", mode=(True, 3, 20))
+    _check(pkg, oracle, R, sc, ramp="$@B%8&WM#*oahkbdpqwmZO0QLCJUYXzcvunxrjft/\\|()1{}[]?-_+~<>i!lI;:,\"^`'. ", mode=(False, 2, 12))
+    _check(pkg, oracle, R, sc, ramp="ab", mode=(True, 1, 5))
+
+
+def test_reference_scenes_from_fixture(pkg, oracle, R, golden_dir):
+    """Scenes of the golden fixture: the reference's default scene (two spheres) and a legacy-format
+    scene with planes (huge triangles that cross the near plane), spheres and ten point lights."""
+    with open(os.path.join(golden_dir, "ref_raster_host.json")) as fh:
+        ref = json.load(fh)
+    seen_large = False
+    for case in ref["cases"]:
+        scene = ref["scenes"][case["scene"]]
+        vbo, idx = pkg.host.build_geometry(scene)
+        if idx.size == 0:
+            continue
+        proj, view = pkg.host.camera_matrices(case["camera"], case["cols"], case["rows"], case["pixelAspect"])
+        sc = {"name": case["scene"] + "/" + case["cam_name"], "vbo": vbo, "idx": idx, "proj": proj, "view": view,
+              "lights": pkg.host.pack_lights(scene), "cols": case["cols"], "rows": case["rows"]}
+        _check(pkg, oracle, R, sc)
+        seen_large = seen_large or R.frame_counters()["large_records"] > 0
+    assert seen_large                  # the plane quads exercised the large-triangle pass
+
+
+def test_c3_million_triangles_1080p(pkg, oracle, R):
+    sc = pkg.scenes.random_scene(1_000_000, 1920, 1080)
+    out, ids = _check(pkg, oracle, R, sc)
+    assert np.unique(ids).size > 200_000
+
+
+def test_c4_same_scene_4k(pkg, oracle, R):
+    sc = pkg.scenes.random_scene(1_000_000, 3840, 2160)
+    _check(pkg, oracle, R, sc, mode=(False, 2, 12))
+
+
+def test_c5_shape_point_lights_dense(pkg, oracle, R):
+    """C5's shape at a size the oracle finishes quickly: 2M triangles, 4 point lights, 1080p."""
+    sc = pkg.scenes.random_scene(2_000_000, 1920, 1080, seed=0xA5C12, point_lights=True)
+    _check(pkg, oracle, R, sc)
+
+
+def test_near_plane_and_huge_triangles(pkg, oracle, R):
+    """Random large triangles all around (and through) the camera: clipping, culling, all three passes."""
+    rng = np.random.default_rng(7)
+    T = 3000
+    centre = rng.uniform(-6, 6, size=(T, 1, 3))
+    P = (centre + rng.uniform(-1, 1, size=(T, 3, 3)) * rng.choice([0.05, 0.5, 4.0, 30.0], size=(T, 1, 1))).reshape(-1, 3)
+    C = rng.uniform(0, 1, size=(T, 3))
+    vbo, idx = pkg.host.mesh_to_vbo(P.astype(np.float32), np.arange(T * 3).reshape(-1, 3), C)
+    for cols, rows, cam in [(200, 100, {"pos": (0.1, 0.2, 0.3), "yaw": 0.7, "pitch": -0.2}),
+                            (97, 61, {"pos": (3, -2, 1), "yaw": -2.0, "pitch": 0.9}),
+                            (1, 1, {"pos": (0, 0, 0), "yaw": 0.0, "pitch": 0.0})]:
+        proj, view = pkg.host.camera_matrices(cam, cols, rows, 0.5)
+        sc = {"name": "soup", "vbo": vbo, "idx": idx, "proj": proj, "view": view,
+              "lights": pkg.host.pack_lights({"lights": {"points": [{"p": [1, 2, 0], "color": [1, 1, 1], "intensity": 4}]}}),
+              "cols": cols, "rows": rows}
+        _check(pkg, oracle, R, sc, label="soup %dx%d" % (cols, rows))
+        if cols == 200:
+            c = R.frame_counters()
+            assert c["medium_records"] > 0 and c["large_records"] > 0
+
+
+def test_shared_edges_have_exactly_one_owner(pkg, R):
+    """A closed, consistently wound mesh seen from outside: no background cell inside the silhouette
+    of the sphere (holes) - checked as: every row's covered cells form one contiguous run."""
+    sc = pkg.scenes.icosphere_scene(angle=0.3, cols=400, rows=400, pixel_aspect=1.0, subdiv=5)
+    pkg.scenes.upload(R, sc)
+    ids = R.render(400, 400, want_ids=True)["ids"]
+    hit = ids != 0xFFFFFFFF
+    assert hit.sum() > 10000
+    for row in hit:
+        xs = np.flatnonzero(row)
+        if xs.size:
+            assert xs[-1] - xs[0] + 1 == xs.size
+
+
+def test_bad_indices_nan_vertices_and_degenerates(pkg, oracle, R):
+    P, I = pkg.geometry.icosphere(2)
+    vbo, idx = pkg.host.mesh_to_vbo(P, I)
+    vbo = vbo.copy(); idx = idx.copy()
+    vbo[5, 0] = np.nan; vbo[40, 2] = np.inf; vbo[90:93, 0:3] = 0.25        # NaN / inf / zero-area
+    idx[30] = 10_000_000                                                    # out of range
+    sc = pkg.scenes.icosphere_scene(subdiv=2, cols=120, rows=50)
+    sc["vbo"], sc["idx"] = vbo, idx
+    _check(pkg, oracle, R, sc)
+
+
+def test_strips_tile_the_full_frame(pkg, oracle, R):
+    sc = pkg.scenes.icosphere_scene(cols=320, rows=180)
+    pkg.scenes.upload(R, sc)
+    full = R.render(320, 180)
+    for n in (2, 3, 8):
+        bounds = [180 * k // n for k in range(n + 1)]
+        asc = np.zeros_like(full["ascii"]); rg = np.zeros_like(full["rgba"]); dp = np.zeros_like(full["depth"])
+        for k in range(n):
+            R.set_strip(bounds[k], bounds[k + 1])
+            o = R.render(320, 180)
+            s = slice(bounds[k], bounds[k + 1])
+            asc[s], rg[s], dp[s] = o["ascii"][s], o["rgba"][s], o["depth"][s]
+        R.set_strip(0, 0)
+        assert np.array_equal(asc, full["ascii"]) and np.array_equal(rg, full["rgba"]) and np.array_equal(dp, full["depth"])
+
+
+def test_repeatable_and_resizable(pkg, R):
+    sc = pkg.scenes.random_scene(200_000, 640, 360)
+    pkg.scenes.upload(R, sc)
+    a = R.render(640, 360, want_ids=True)
+    R.render(96, 36)
+    b = R.render(640, 360, want_ids=True)
+    for k in ("rgba", "depth", "ascii", "ids"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_no_geometry_leaves_buffers_untouched(pkg, R):
+    R.set_mesh(np.zeros((0, 9), np.float32), np.zeros(0, np.uint32))
+    fb = np.full((36, 96, 4), 7, dtype=np.uint8)
+    asc = np.full((36, 96), 9, dtype=np.uint8)
+    R.render_into(96, 36, rgba=fb, ascii=asc)
+    assert np.all(fb == 7) and np.all(asc == 9)          # raster.js:274: early return
+
+
+def test_argument_errors(pkg, R):
+    with pytest.raises(pkg.AsciiRastError):
+        R.render_async(0, 10)
+    with pytest.raises(pkg.AsciiRastError):
+        R.set_ascii("", True, 2, 12)
+    with pytest.raises(pkg.AsciiRastError):
+        R.set_lights({"ambient": [0, 0, 0], "dir": [0, 1, 0], "dir_color": [1, 1, 1],
+                      "pl_pos": np.zeros((9, 3)), "pl_col": np.zeros((9, 3))})
+    with pytest.raises(pkg.AsciiRastError):
+        pkg.Renderer(99)
+
+
+def test_quantize_entry_point_vs_reference_vectors(pkg, oracle, R, golden_dir):
+    with open(os.path.join(golden_dir, "ref_quantize.json")) as fh:
+        ref = json.load(fh)
+    for case in ref["cases"]:
+        rgba = np.frombuffer(base64.b64decode(case["rgba"]), dtype=np.uint8).copy()
+        want = np.frombuffer(base64.b64decode(case["chars_u16"]), dtype=np.uint16)
+        if "ui" in case:
+            ui = np.asarray(case["ui"], dtype=np.uint8)
+            rgba.reshape(-1, 4)[:, 3] = np.where(ui > 0, ui, 1)
+        else:
+            rgba.reshape(-1, 4)[:, 3] = 255
+        R.set_ascii(case["ramp"], False, 2, 12)
+        got = R.quantize(rgba, case["cols"], case["rows"])
+        assert np.array_equal(got.reshape(-1).astype(np.uint16), want), (case["name"], case["ramp"])
+
+
+def test_quantize_modal_vs_oracle(pkg, oracle, R):
+    rng = np.random.default_rng(3)
+    for cols, rows, radius, thresh in [(96, 36, 2, 12), (333, 77, 3, 20), (5, 3, 1, 3), (1920, 1080, 2, 12)]:
+        lv = rng.choice([0, 40, 90, 140, 250], size=(rows * cols, 1)).astype(np.uint8)
+        rgba = np.concatenate([lv, lv // 2 + 10, lv, np.full_like(lv, 255)], axis=1)
+        ov = rng.random(rows * cols) < 0.05
+        rgba[ov, 3] = rng.integers(0, 256, size=ov.sum())
+        R.set_ascii("@%#*+=-:. ", True, radius, thresh)
+        got = R.quantize(rgba, cols, rows)
+        want = oracle.quantize(rgba, cols, rows, "@%#*+=-:. ", 1, radius, thresh)
+        assert np.array_equal(got, want), (cols, rows)

@@ -1,0 +1,63 @@
+"""World-size-2 (and 4) CPU rehearsal of the strip partition + all-gather used for multi-GPU runs.
+The oracle stands in for the per-rank renderer here (this is a test of the partition / gather logic,
+not of the HIP path)."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ar = importlib.import_module("ascii-renderer_amd")
+    mg = importlib.import_module("ascii-renderer_amd.multigpu")
+    from oracle import oracle as orc
+    cols, rows = 96, 48
+    sc = ar.scenes.icosphere_scene(cols=cols, rows=rows, subdiv=2)
+    row0, row1 = mg.strip_bounds(rows, world, rank)
+    rgba, _d, _i = orc.render(sc["vbo"], sc["idx"], sc["proj"], sc["view"], sc["lights"], cols, rows)
+    full = orc.quantize(rgba, cols, rows, ar.scenes.DEFAULT_RAMP, 1, 2, 12)
+    local = torch.from_numpy(full[row0:row1].copy())          # this rank's band only
+    got = mg.all_gather_strips(local)
+    ok = np.array_equal(got.numpy(), full)
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        with open(tmp, "w") as fh:
+            fh.write(str(int(flag.item())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_strip_all_gather_reassembles_the_frame(world, tmp_path):
+    out = str(tmp_path / "ok.txt")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert open(out).read() == "1"
+
+
+def test_strip_bounds(pkg):
+    mg = importlib.import_module("ascii-renderer_amd.multigpu")
+    assert [mg.strip_bounds(1080, 8, r) for r in range(8)] == [(135 * r, 135 * (r + 1)) for r in range(8)]
+    assert mg.strip_bounds(2160, 1, 0) == (0, 2160)
+    with pytest.raises(ValueError):
+        mg.strip_bounds(1080, 7, 0)
+    with pytest.raises(ValueError):
+        mg.strip_bounds(1080, 2, 2)
