@@ -229,7 +229,8 @@ static void raster_tri(const orc_vert t[3], uint32_t tri_id, const orc_lights *L
  * Render one frame.  vbo9: n_verts x (pos3, nrm3, col3) binary32 (raster.js:222-236); idx: n_tris x 3
  * u32 (raster.js:249).  proj/view: column-major binary32 as uploaded by raster.js:303-304.  Lights as
  * packed by raster.js:307-342.  Outputs are TOP-DOWN (row 0 = top): rgba_out cols*rows*4, depth_out
- * cols*rows (1.0 = background), ids_out cols*rows (0xFFFFFFFF = background); any may be NULL.
+ * cols*rows (1.0 = background), ids_out cols*rows (2*triangle + sub-triangle of the winner,
+ * 0xFFFFFFFF = background); any may be NULL.
  * Triangles naming a vertex >= n_verts are skipped.  Returns 0, or -1 on bad arguments.
  */
 int orc_render(const float *vbo9, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris,
@@ -265,7 +266,7 @@ int orc_render(const float *vbo9, uint32_t n_verts, const uint32_t *idx, uint32_
         vertex_shader(PV, vbo9 + (size_t)i1 * 9, &in[1]);
         vertex_shader(PV, vbo9 + (size_t)i2 * 9, &in[2]);
         const int ns = clip_near(in, sub);
-        for (int s = 0; s < ns; s++) raster_tri(sub[s], t, &L, cols, rows, rgba, depth, ids);
+        for (int s = 0; s < ns; s++) raster_tri(sub[s], 2u * t + (uint32_t)s, &L, cols, rows, rgba, depth, ids);
     }
     for (int r = 0; r < rows; r++) {                /* flipAndCopy: output row r = GL row rows-1-r */
         const size_t src = (size_t)(rows - 1 - r) * cols, dst = (size_t)r * cols;
