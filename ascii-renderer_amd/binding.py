@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libascii_rast.so")
 N_KERNELS = 8
 EXPORTS = [
     "ar_create", "ar_destroy", "ar_last_error", "ar_set_mesh", "ar_set_camera", "ar_set_lights",
-    "ar_set_ascii", "ar_set_strip", "ar_render", "ar_render_async", "ar_sync", "ar_read",
+    "ar_set_ascii", "ar_set_strip", "ar_set_id_output", "ar_render", "ar_render_async", "ar_sync", "ar_read",
     "ar_device_buffer", "ar_stream", "ar_quantize", "ar_set_profiling", "ar_kernel_stats",
     "ar_frame_counters",
 ]
@@ -49,6 +49,7 @@ def load_library():
     L.ar_set_lights.argtypes = [vp, _fp, _fp, _fp, ctypes.c_int, _fp, _fp]
     L.ar_set_ascii.argtypes = [vp, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.ar_set_strip.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    L.ar_set_id_output.argtypes = [vp, ctypes.c_int]
     L.ar_render.argtypes = [vp, ctypes.c_int, ctypes.c_int, _u8p, _fp, _u8p]
     L.ar_render_async.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     L.ar_sync.argtypes = [vp]
@@ -61,7 +62,7 @@ def load_library():
     L.ar_set_profiling.argtypes = [vp, ctypes.c_int]
     L.ar_kernel_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), _u32p, _fp]
     L.ar_frame_counters.argtypes = [vp, _u32p]
-    for name in ("ar_set_mesh", "ar_set_camera", "ar_set_lights", "ar_set_ascii", "ar_set_strip", "ar_render",
+    for name in ("ar_set_id_output", "ar_set_mesh", "ar_set_camera", "ar_set_lights", "ar_set_ascii", "ar_set_strip", "ar_set_id_output", "ar_render",
                  "ar_render_async", "ar_sync", "ar_read", "ar_quantize", "ar_set_profiling", "ar_kernel_stats",
                  "ar_frame_counters"):
         getattr(L, name).restype = ctypes.c_int
@@ -134,6 +135,7 @@ class Renderer:
 
     def render(self, cols, rows, want_ids=False):
         """Blocking frame; returns dict(rgba, depth, ascii[, ids])."""
+        self._check(self._L.ar_set_id_output(self._h, int(bool(want_ids))))
         self.render_async(cols, rows)
         return self.read(want_ids=want_ids)
 

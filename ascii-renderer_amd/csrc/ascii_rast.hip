@@ -27,6 +27,10 @@
 
 #include "ascii_rast.h"
 
+#ifndef AR_EXP
+#define AR_EXP 0
+#endif
+
 namespace {
 
 constexpr uint64_t kBackgroundKey = (uint64_t(0x3F800000u) << 32) | 0xFFFFFFFFull;  // depth 1.0f
@@ -51,6 +55,7 @@ struct FrameParams {
     float hw, hh;    // cols/2, rows/2
     uint32_t n_tris, n_verts;
     int ramp_len, mode_on, mode_radius, mode_thresh;
+    int want_ids;    // also store the winning (2*triangle + sub) per cell
     uint8_t ramp[AR_MAX_RAMP];
 };
 
@@ -188,9 +193,9 @@ __device__ __forceinline__ bool edge_inside(double E, double a, double b) {
 template <typename R>
 __device__ __forceinline__ bool cover(const R &e, int i, int j, float (&f)[3], float &zw) {
     const double px = double(i) + 0.5, py = double(j) + 0.5;
-    const double E0 = (e.a[0] * px + e.b[0] * py) + e.c[0];
-    const double E1 = (e.a[1] * px + e.b[1] * py) + e.c[1];
-    const double E2 = (e.a[2] * px + e.b[2] * py) + e.c[2];
+    const double E0 = e.a[0] * px + (e.b[0] * py + e.c[0]);  // row term first: it is invariant along a row
+    const double E1 = e.a[1] * px + (e.b[1] * py + e.c[1]);
+    const double E2 = e.a[2] * px + (e.b[2] * py + e.c[2]);
     if (!edge_inside(E0, e.a[0], e.b[0]) || !edge_inside(E1, e.a[1], e.b[1]) || !edge_inside(E2, e.a[2], e.b[2]))
         return false;
     f[0] = float(E0); f[1] = float(E1); f[2] = float(E2);
@@ -226,6 +231,10 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const float *__r
     const uint32_t v0 = idx[3 * size_t(t)], v1 = idx[3 * size_t(t) + 1], v2 = idx[3 * size_t(t) + 2];
     if (v0 >= fp.n_verts || v1 >= fp.n_verts || v2 >= fp.n_verts) return;
     const Vert<0> in0 = load_vertex<0>(fp, vbo, v0), in1 = load_vertex<0>(fp, vbo, v1), in2 = load_vertex<0>(fp, vbo, v2);
+#if AR_EXP == 3
+    if (in0.c[0] + in1.c[1] + in2.c[2] + in0.c[3] + in1.c[3]+ in2.c[0] == 0.123f) vis[0] = t;
+    return;
+#endif
     Vert<0> s0[3], s1[3];
     const int ns = clip_near<0>(in0, in1, in2, s0, s1);
     const int jlo = fp.rows - fp.yb, jhi = fp.rows - 1 - fp.ya;  // window rows of the rendered strip
@@ -256,11 +265,19 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const float *__r
             }
             // queue full: fall through and scan the range here (slow but correct)
         }
+#if AR_EXP == 2
+        if (ncells == 12345678) vis[0] = id;
+        continue;
+#endif
         for (int j = j0; j <= j1; j++) {
             const size_t row = size_t(fp.rows - 1 - j) * fp.cols;
             for (int i = i0; i <= i1; i++) {
                 float f[3], zw;
+#if AR_EXP == 1
+                if (cover(e, i, j, f, zw) && zw == 0.123f) vis_min(vis, row + i, make_key(zw, id));
+#else
                 if (cover(e, i, j, f, zw)) vis_min(vis, row + i, make_key(zw, id));
+#endif
             }
         }
     }
@@ -351,10 +368,17 @@ __device__ __forceinline__ void shade(const FrameParams &fp, const float (&v)[9]
 }
 
 // One lane per cell of output rows [ya, yb): rebuild the winner's setup, interpolate, shade, store.
+// The cell's visibility key is put back to "background" here, so the next frame needs no clear pass;
+// lane 0 of block 0 retires the frame's queue counters (cnt[0..1] live, cnt[2..3] = last frame).
 __global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__restrict__ vbo,
-                                               const uint32_t *__restrict__ idx, const uint64_t *__restrict__ vis,
+                                               const uint32_t *__restrict__ idx, uint64_t *__restrict__ vis,
                                                uint8_t *__restrict__ rgba, float *__restrict__ depth,
-                                               uint8_t *__restrict__ ascii) {
+                                               uint8_t *__restrict__ ascii, uint8_t *__restrict__ ridx,
+                                               uint32_t *__restrict__ ids, uint32_t *__restrict__ cnt) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        cnt[2] = cnt[0]; cnt[3] = cnt[1];
+        cnt[0] = 0; cnt[1] = 0;
+    }
     const size_t n = size_t(fp.yb - fp.ya) * fp.cols;
     const size_t p = size_t(blockIdx.x) * 256 + threadIdx.x;
     if (p >= n) return;
@@ -365,6 +389,7 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__re
     uint8_t px[4] = {0, 0, 0, 255};
     float zw = 1.0f;
     if (key != kBackgroundKey) {
+        vis[cell] = kBackgroundKey;
         const uint32_t id = uint32_t(key), t = id >> 1, sub = id & 1u;
         const uint32_t v0 = idx[3 * size_t(t)], v1 = idx[3 * size_t(t) + 1], v2 = idx[3 * size_t(t) + 2];
         const Vert<9> in0 = load_vertex<9>(fp, vbo, v0), in1 = load_vertex<9>(fp, vbo, v1), in2 = load_vertex<9>(fp, vbo, v2);
@@ -385,50 +410,89 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__re
     *reinterpret_cast<uint32_t *>(rgba + cell * 4) =
         uint32_t(px[0]) | (uint32_t(px[1]) << 8) | (uint32_t(px[2]) << 16) | (uint32_t(px[3]) << 24);
     depth[cell] = zw;
-    if (!fp.mode_on && r >= fp.row0 && r < fp.row1) ascii[cell] = fp.ramp[ramp_index(px[0], px[1], px[2], fp.ramp_len)];
+    if (fp.want_ids) ids[cell] = uint32_t(key);
+    const int ri = ramp_index(px[0], px[1], px[2], fp.ramp_len);
+    if (fp.mode_on) ridx[cell] = uint8_t(ri);  // input of the smoothing pass
+    else if (r >= fp.row0 && r < fp.row1) ascii[cell] = fp.ramp[ri];
 }
 
-// ASCII stage over an RGBA8 grid: alpha 2..254 is a literal code, otherwise ramp quantisation with
-// optional modal smoothing (ascii_pass_shader.js:77-138,153-188).  One lane per cell of rows [row0,row1).
-__global__ __launch_bounds__(256) void k_ascii(FrameParams fp, const uint8_t *__restrict__ rgba,
-                                               uint8_t *__restrict__ ascii) {
-    const size_t n = size_t(fp.row1 - fp.row0) * fp.cols;
+// ASCII stage without smoothing over an RGBA8 grid: alpha 2..254 is a literal code, otherwise the ramp.
+__global__ __launch_bounds__(256) void k_quantize_plain(FrameParams fp, const uint32_t *__restrict__ px,
+                                                        uint8_t *__restrict__ ascii, size_t n) {
     const size_t p = size_t(blockIdx.x) * 256 + threadIdx.x;
     if (p >= n) return;
-    const size_t cell = size_t(fp.row0) * fp.cols + p;
-    const int y = int(cell / fp.cols), x = int(cell - size_t(y) * fp.cols);
-    const uint32_t *px = reinterpret_cast<const uint32_t *>(rgba);
-    const uint32_t me = px[cell];
+    const uint32_t me = px[p];
     const int a = int(me >> 24);
-    if (a >= 2 && a <= 254) { ascii[cell] = uint8_t(a); return; }
-    const int base = ramp_index(int(me & 255u), int((me >> 8) & 255u), int((me >> 16) & 255u), fp.ramp_len);
-    int fin = base;
-    if (fp.mode_on == 1) {
-        int radius = fp.mode_radius;
-        radius = radius < 1 ? 1 : (radius > 3 ? 3 : radius);
-        int cand = -1, cnt = 0, votes = 0;
-        for (int pass = 0; pass < 2; pass++) {
-            if (pass == 1 && cand < 0) break;
-            for (int dy = -radius; dy <= radius; dy++) {
-                const int ny = min(max(y + dy, 0), fp.rows - 1);
-                for (int dx = -radius; dx <= radius; dx++) {
-                    if (dx == 0 && dy == 0) continue;
-                    const int nx = min(max(x + dx, 0), fp.cols - 1);
-                    const uint32_t q = px[size_t(ny) * fp.cols + nx];
-                    const int qa = int(q >> 24);
-                    if (qa >= 2 && qa <= 254) continue;
-                    const int ni = ramp_index(int(q & 255u), int((q >> 8) & 255u), int((q >> 16) & 255u), fp.ramp_len);
-                    if (pass == 0) {
-                        if (cnt == 0) { cand = ni; cnt = 1; }
-                        else if (ni == cand) cnt += 1;
-                        else cnt -= 1;
-                    } else if (ni == cand) votes += 1;
-                }
-            }
+    ascii[p] = (a >= 2 && a <= 254)
+                   ? uint8_t(a)
+                   : fp.ramp[ramp_index(int(me & 255u), int((me >> 8) & 255u), int((me >> 16) & 255u), fp.ramp_len)];
+}
+
+// Modal smoothing (ascii_pass_shader.js:77-138,169-185) over rows [row0, row1): a 32x8 tile of cells
+// per workgroup, ramp indices of the tile and its halo of R cells staged in LDS (grid-clamped, as the
+// shader's clampCell does), -1 marking alpha-override cells, which neither vote nor get smoothed.
+// FROM_RGBA: src is an RGBA8 grid (AsciiPass.drawFromBuffer input); otherwise a plane of ramp
+// indices written by k_shade (rendered frames carry no overrides).
+template <int R, bool FROM_RGBA>
+__global__ __launch_bounds__(256) void k_ascii(FrameParams fp, const void *__restrict__ src, uint8_t *__restrict__ ascii) {
+    constexpr int TW = 32 + 2 * R, TH = 8 + 2 * R;
+    __shared__ int16_t tile[TW * TH];
+    const int x0 = int(blockIdx.x) * 32, y0 = fp.row0 + int(blockIdx.y) * 8;
+    for (int k = int(threadIdx.x); k < TW * TH; k += 256) {
+        const int ty = k / TW, tx = k - ty * TW;
+        const int gx = min(max(x0 + tx - R, 0), fp.cols - 1), gy = min(max(y0 + ty - R, 0), fp.rows - 1);
+        const size_t g = size_t(gy) * fp.cols + gx;
+        int val;
+        if (FROM_RGBA) {
+            const uint32_t q = static_cast<const uint32_t *>(src)[g];
+            const int qa = int(q >> 24);
+            val = (qa >= 2 && qa <= 254) ? -1 : ramp_index(int(q & 255u), int((q >> 8) & 255u), int((q >> 16) & 255u), fp.ramp_len);
+        } else {
+            val = static_cast<const uint8_t *>(src)[g];
         }
-        if (cand >= 0 && votes >= fp.mode_thresh && cand != base) fin = cand;
+        tile[k] = int16_t(val);
     }
+    __syncthreads();
+    const int lx = int(threadIdx.x & 31u), ly = int(threadIdx.x >> 5);
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= fp.cols || y >= fp.row1) return;
+    const size_t cell = size_t(y) * fp.cols + x;
+    const int base = tile[(ly + R) * TW + lx + R];
+    if (FROM_RGBA && base < 0) {
+        ascii[cell] = uint8_t(static_cast<const uint32_t *>(src)[cell] >> 24);
+        return;
+    }
+    int nb[(2 * R + 1) * (2 * R + 1) - 1];
+    {
+        int q = 0;
+#pragma unroll
+        for (int dy = -R; dy <= R; dy++)
+#pragma unroll
+            for (int dx = -R; dx <= R; dx++)
+                if (dx != 0 || dy != 0) nb[q++] = tile[(ly + R + dy) * TW + lx + R + dx];
+    }
+    int cand = -1, cnt = 0, votes = 0;  // Boyer-Moore candidate in shader order, then its true vote count
+#pragma unroll
+    for (int q = 0; q < (2 * R + 1) * (2 * R + 1) - 1; q++) {
+        const int ni = nb[q];
+        if (ni < 0) continue;
+        if (cnt == 0) { cand = ni; cnt = 1; }
+        else if (ni == cand) cnt += 1;
+        else cnt -= 1;
+    }
+#pragma unroll
+    for (int q = 0; q < (2 * R + 1) * (2 * R + 1) - 1; q++) votes += (nb[q] >= 0 && nb[q] == cand) ? 1 : 0;
+    const int fin = (cand >= 0 && votes >= fp.mode_thresh && cand != base) ? cand : base;
     ascii[cell] = (fin >= 0 && fin < fp.ramp_len) ? fp.ramp[fin] : uint8_t(32);
+}
+
+template <bool FROM_RGBA>
+void launch_ascii(const FrameParams &fp, const void *src, uint8_t *ascii, hipStream_t stream) {
+    const dim3 grid((fp.cols + 31) / 32, (fp.row1 - fp.row0 + 7) / 8);
+    const int radius = fp.mode_radius < 1 ? 1 : (fp.mode_radius > 3 ? 3 : fp.mode_radius);  // shader clamps to 1..3
+    if (radius == 1) k_ascii<1, FROM_RGBA><<<grid, 256, 0, stream>>>(fp, src, ascii);
+    else if (radius == 2) k_ascii<2, FROM_RGBA><<<grid, 256, 0, stream>>>(fp, src, ascii);
+    else k_ascii<3, FROM_RGBA><<<grid, 256, 0, stream>>>(fp, src, ascii);
 }
 
 thread_local char g_create_error[256] = "";
@@ -449,9 +513,12 @@ struct ar_ctx {
     uint8_t *d_rgba = nullptr;
     float *d_depth = nullptr;
     uint8_t *d_ascii = nullptr;
+    uint8_t *d_ridx = nullptr;   // ramp index per cell (input of the smoothing pass)
+    uint32_t *d_ids = nullptr;   // winner per cell, allocated when id output is switched on
+    bool want_ids = false;
+    bool vis_clean = false;      // every key of d_vis is "background" (k_shade restores this each frame)
     TriRec *d_medium = nullptr, *d_large = nullptr;
-    uint32_t *d_counters = nullptr;
-    uint32_t *h_counters = nullptr;  // pinned
+    uint32_t *d_counters = nullptr;  // [0..1] live queue counters, [2..3] those of the last frame
     uint8_t *d_q_rgba = nullptr, *d_q_ascii = nullptr;
     size_t q_cells = 0;
     bool rendered = false;
@@ -508,26 +575,36 @@ struct Stamper {  // brackets one launch with events when profiling is on
 
 int free_targets(ar_ctx *ctx) {
     (void)hipFree(ctx->d_vis); (void)hipFree(ctx->d_rgba); (void)hipFree(ctx->d_depth); (void)hipFree(ctx->d_ascii);
+    (void)hipFree(ctx->d_ridx); (void)hipFree(ctx->d_ids);
     ctx->d_vis = nullptr; ctx->d_rgba = nullptr; ctx->d_depth = nullptr; ctx->d_ascii = nullptr;
+    ctx->d_ridx = nullptr; ctx->d_ids = nullptr;
     ctx->cols = ctx->rows = 0;
     ctx->rendered = false;
+    ctx->vis_clean = false;
     return 0;
 }
 
 int ensure_targets(ar_ctx *ctx, int cols, int rows) {
-    if (ctx->d_vis && ctx->cols == cols && ctx->rows == rows) return 0;
-    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    free_targets(ctx);
     const size_t n = size_t(cols) * rows;
-    AR_HIP(ctx, hipMalloc(&ctx->d_vis, n * sizeof(uint64_t)));
-    AR_HIP(ctx, hipMalloc(&ctx->d_rgba, n * 4));
-    AR_HIP(ctx, hipMalloc(&ctx->d_depth, n * sizeof(float)));
-    AR_HIP(ctx, hipMalloc(&ctx->d_ascii, n));
-    // rows outside a strip are never written by the kernels: give them defined contents once
-    AR_HIP(ctx, hipMemsetAsync(ctx->d_rgba, 0, n * 4, ctx->stream));
-    AR_HIP(ctx, hipMemsetAsync(ctx->d_depth, 0, n * sizeof(float), ctx->stream));
-    AR_HIP(ctx, hipMemsetAsync(ctx->d_ascii, 0, n, ctx->stream));
-    ctx->cols = cols; ctx->rows = rows;
+    if (!(ctx->d_vis && ctx->cols == cols && ctx->rows == rows)) {
+        AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        free_targets(ctx);
+        AR_HIP(ctx, hipMalloc(&ctx->d_vis, n * sizeof(uint64_t)));
+        AR_HIP(ctx, hipMalloc(&ctx->d_rgba, n * 4));
+        AR_HIP(ctx, hipMalloc(&ctx->d_depth, n * sizeof(float)));
+        AR_HIP(ctx, hipMalloc(&ctx->d_ascii, n));
+        AR_HIP(ctx, hipMalloc(&ctx->d_ridx, n));
+        // rows outside a strip are never written by the kernels: give them defined contents once
+        AR_HIP(ctx, hipMemsetAsync(ctx->d_rgba, 0, n * 4, ctx->stream));
+        AR_HIP(ctx, hipMemsetAsync(ctx->d_depth, 0, n * sizeof(float), ctx->stream));
+        AR_HIP(ctx, hipMemsetAsync(ctx->d_ascii, 0, n, ctx->stream));
+        AR_HIP(ctx, hipMemsetAsync(ctx->d_ridx, 0, n, ctx->stream));
+        ctx->cols = cols; ctx->rows = rows;
+    }
+    if (ctx->want_ids && !ctx->d_ids) {
+        AR_HIP(ctx, hipMalloc(&ctx->d_ids, n * sizeof(uint32_t)));
+        AR_HIP(ctx, hipMemsetAsync(ctx->d_ids, 0xFF, n * sizeof(uint32_t), ctx->stream));
+    }
     return 0;
 }
 
@@ -543,6 +620,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
     fp.cols = cols; fp.rows = rows;
     fp.hw = float(cols) * 0.5f; fp.hh = float(rows) * 0.5f;
     fp.n_tris = ctx->n_tris; fp.n_verts = ctx->n_verts;
+    fp.want_ids = ctx->want_ids ? 1 : 0;
     int row0 = 0, row1 = rows;
     if (ctx->strip1 > ctx->strip0) {
         if (ctx->strip1 > rows) return fail(ctx, AR_E_ARG, "strip [%d,%d) exceeds %d rows", ctx->strip0, ctx->strip1, rows);
@@ -556,11 +634,14 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
 
     const size_t strip_cells = size_t(fp.yb - fp.ya) * cols;
     const unsigned cell_blocks = unsigned((strip_cells + 255) / 256);
-    AR_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
-    {
+    const bool was_clean = ctx->vis_clean;
+    ctx->vis_clean = false;  // stays false if anything below fails: the next frame then clears again
+    if (!was_clean) {
+        // first frame on these targets (or after a failed one); in steady state k_shade leaves every
+        // key it consumed at "background" and the queue counters at zero
+        AR_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
         Stamper s(ctx, K_CLEAR);
-        const unsigned blocks = cell_blocks < 2048u ? cell_blocks : 2048u;
-        k_clear<<<blocks, 256, 0, ctx->stream>>>(ctx->d_vis, size_t(fp.ya) * cols, strip_cells);
+        k_clear<<<2048, 256, 0, ctx->stream>>>(ctx->d_vis, 0, size_t(cols) * rows);
     }
     {
         Stamper s(ctx, K_RASTER);
@@ -569,7 +650,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
     }
     {
         Stamper s(ctx, K_MEDIUM);
-        k_raster_medium<<<1024, 256, 0, ctx->stream>>>(fp, ctx->d_vis, ctx->d_medium, ctx->d_counters);
+        k_raster_medium<<<512, 256, 0, ctx->stream>>>(fp, ctx->d_vis, ctx->d_medium, ctx->d_counters);
     }
     {
         Stamper s(ctx, K_LARGE);
@@ -579,15 +660,14 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
     {
         Stamper s(ctx, K_SHADE);
         k_shade<<<cell_blocks, 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_vis, ctx->d_rgba, ctx->d_depth,
-                                                     ctx->d_ascii);
+                                                     ctx->d_ascii, ctx->d_ridx, ctx->d_ids, ctx->d_counters);
     }
     if (fp.mode_on == 1) {
         Stamper s(ctx, K_ASCII);
-        const size_t out_cells = size_t(row1 - row0) * cols;
-        k_ascii<<<unsigned((out_cells + 255) / 256), 256, 0, ctx->stream>>>(fp, ctx->d_rgba, ctx->d_ascii);
+        launch_ascii<false>(fp, ctx->d_ridx, ctx->d_ascii, ctx->stream);
     }
-    AR_HIP(ctx, hipMemcpyAsync(ctx->h_counters, ctx->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     AR_HIP(ctx, hipGetLastError());
+    ctx->vis_clean = true;
     ctx->rendered = true;
     return 0;
 }
@@ -608,13 +688,12 @@ ar_ctx *ar_create(int device_id) {
               hipMalloc(&ctx->d_medium, size_t(kMediumCapacity) * sizeof(TriRec)) == hipSuccess &&
               hipMalloc(&ctx->d_large, size_t(kLargeCapacity) * sizeof(TriRec)) == hipSuccess &&
               hipMalloc(&ctx->d_counters, 4 * sizeof(uint32_t)) == hipSuccess &&
-              hipHostMalloc(&ctx->h_counters, 4 * sizeof(uint32_t)) == hipSuccess;
+              hipMemset(ctx->d_counters, 0, 4 * sizeof(uint32_t)) == hipSuccess;
     if (!ok) {
         fail(nullptr, AR_E_HIP, "context setup failed: %s", hipGetErrorString(hipGetLastError()));
         ar_destroy(ctx);
         return nullptr;
     }
-    memset(ctx->h_counters, 0, 4 * sizeof(uint32_t));
     memset(&ctx->fp, 0, sizeof ctx->fp);
     static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     memcpy(ctx->proj, ident, sizeof ident);
@@ -636,7 +715,6 @@ void ar_destroy(ar_ctx *ctx) {
     (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx);
     (void)hipFree(ctx->d_medium); (void)hipFree(ctx->d_large); (void)hipFree(ctx->d_counters);
     (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii);
-    if (ctx->h_counters) (void)hipHostFree(ctx->h_counters);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -725,9 +803,8 @@ int ar_read(ar_ctx *ctx, uint8_t *rgba, float *depth, uint8_t *ascii, uint32_t *
     if (depth) AR_HIP(ctx, hipMemcpy(depth, ctx->d_depth, n * sizeof(float), hipMemcpyDeviceToHost));
     if (ascii) AR_HIP(ctx, hipMemcpy(ascii, ctx->d_ascii, n, hipMemcpyDeviceToHost));
     if (ids) {
-        std::vector<uint64_t> keys(n);
-        AR_HIP(ctx, hipMemcpy(keys.data(), ctx->d_vis, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        for (size_t p = 0; p < n; p++) ids[p] = uint32_t(keys[p]);
+        if (!ctx->d_ids) return fail(ctx, AR_E_STATE, "ar_read: ids wanted but ar_set_id_output was not on for the last frame");
+        AR_HIP(ctx, hipMemcpy(ids, ctx->d_ids, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     return 0;
 }
@@ -771,11 +848,18 @@ int ar_quantize(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *a
     AR_HIP(ctx, hipMemcpyAsync(ctx->d_q_rgba, rgba, n * 4, hipMemcpyHostToDevice, ctx->stream));
     {
         Stamper s(ctx, K_ASCII);
-        k_ascii<<<unsigned((n + 255) / 256), 256, 0, ctx->stream>>>(fp, ctx->d_q_rgba, ctx->d_q_ascii);
+        if (fp.mode_on == 1) launch_ascii<true>(fp, ctx->d_q_rgba, ctx->d_q_ascii, ctx->stream);
+        else k_quantize_plain<<<unsigned((n + 255) / 256), 256, 0, ctx->stream>>>(fp, reinterpret_cast<const uint32_t *>(ctx->d_q_rgba), ctx->d_q_ascii, n);
     }
     AR_HIP(ctx, hipGetLastError());
     AR_HIP(ctx, hipMemcpyAsync(ascii, ctx->d_q_ascii, n, hipMemcpyDeviceToHost, ctx->stream));
     AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ar_set_id_output(ar_ctx *ctx, int on) {
+    if (!ctx) return AR_E_ARG;
+    ctx->want_ids = on != 0;
     return 0;
 }
 
@@ -811,9 +895,11 @@ int ar_frame_counters(ar_ctx *ctx, uint32_t out[4]) {
     if (!ctx || !out) return AR_E_ARG;
     AR_HIP(ctx, hipSetDevice(ctx->device));
     AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t c[4] = {0, 0, 0, 0};
+    AR_HIP(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
     out[0] = ctx->n_tris;
-    out[1] = ctx->h_counters[0];
-    out[2] = ctx->h_counters[1];
+    out[1] = c[2];
+    out[2] = c[3];
     out[3] = 0;
     return 0;
 }

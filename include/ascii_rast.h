@@ -73,8 +73,11 @@ int ar_set_strip(ar_ctx *ctx, int row0, int row1);
 int ar_render(ar_ctx *ctx, int cols, int rows, uint8_t *rgba, float *depth, uint8_t *ascii);
 
 /* The same frame without the device->host copies: enqueue on the context's stream / wait for it /
- * copy out what is wanted afterwards (ids = per cell 2*triangle + sub-triangle, 0xFFFFFFFF background).
- * Lets a caller keep the outputs resident in HBM (benchmarks, multi-GPU gathers). */
+ * copy out what is wanted afterwards.  Lets a caller keep the outputs resident in HBM (benchmarks,
+ * multi-GPU gathers).  ids (per cell 2*triangle + sub-triangle of the winner, 0xFFFFFFFF background;
+ * a debugging output with no counterpart in the reference) is only produced by frames rendered
+ * after ar_set_id_output(ctx, 1). */
+int ar_set_id_output(ar_ctx *ctx, int on);
 int ar_render_async(ar_ctx *ctx, int cols, int rows);
 int ar_sync(ar_ctx *ctx);
 int ar_read(ar_ctx *ctx, uint8_t *rgba, float *depth, uint8_t *ascii, uint32_t *ids);

@@ -38,7 +38,7 @@
  *     handled by scanning only cells of the viewport, far by the depth test against the clear value.
  *   - pixel-homogeneous vertex (X,Y,W) = ((x_c + w_c)*cols/2, (y_c + w_c)*rows/2, w_c) in binary32,
  *     GL window orientation (y up).  Edge functions are the cross products of those vectors taken in
- *     binary64 (a,b,c) and evaluated in binary64 at cell centres (i+0.5, j+0.5): E = (a*px + b*py) + c.
+ *     binary64 (a,b,c) and evaluated in binary64 at cell centres (i+0.5, j+0.5): E = a*px + (b*py + c).
  *     det = (X0*a0 + Y0*b0) + W0*c0 in binary64; det <= 0 is culled (back face or zero area).
  *     A cell is covered when every E_k > 0, or E_k == 0 on an edge with a_k > 0 or (a_k == 0 and
  *     b_k > 0) - a top-left style rule that gives exactly one owner on a shared edge because the
@@ -201,9 +201,9 @@ static void raster_tri(const orc_vert t[3], uint32_t tri_id, const orc_lights *L
         const double py = (double)j + 0.5;
         for (int i = i0; i <= i1; i++) {
             const double px = (double)i + 0.5;
-            const double E0 = (a[0] * px + b[0] * py) + c[0];
-            const double E1 = (a[1] * px + b[1] * py) + c[1];
-            const double E2 = (a[2] * px + b[2] * py) + c[2];
+            const double E0 = a[0] * px + (b[0] * py + c[0]);
+            const double E1 = a[1] * px + (b[1] * py + c[1]);
+            const double E2 = a[2] * px + (b[2] * py + c[2]);
             if (!edge_inside(E0, a[0], b[0]) || !edge_inside(E1, a[1], b[1]) || !edge_inside(E2, a[2], b[2]))
                 continue;
             const float f0 = (float)E0, f1 = (float)E1, f2 = (float)E2;
