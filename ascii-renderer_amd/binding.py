@@ -14,7 +14,7 @@ EXPORTS = [
     "ar_create", "ar_destroy", "ar_last_error", "ar_set_mesh", "ar_set_camera", "ar_set_lights",
     "ar_set_ascii", "ar_set_strip", "ar_set_id_output", "ar_render", "ar_render_async", "ar_sync", "ar_read",
     "ar_device_buffer", "ar_stream", "ar_quantize", "ar_set_profiling", "ar_kernel_stats",
-    "ar_frame_counters",
+    "ar_frame_counters", "ar_set_option",
 ]
 _lib = None
 
@@ -62,9 +62,10 @@ def load_library():
     L.ar_set_profiling.argtypes = [vp, ctypes.c_int]
     L.ar_kernel_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), _u32p, _fp]
     L.ar_frame_counters.argtypes = [vp, _u32p]
+    L.ar_set_option.argtypes = [vp, ctypes.c_int, ctypes.c_longlong]
     for name in ("ar_set_id_output", "ar_set_mesh", "ar_set_camera", "ar_set_lights", "ar_set_ascii", "ar_set_strip", "ar_set_id_output", "ar_render",
                  "ar_render_async", "ar_sync", "ar_read", "ar_quantize", "ar_set_profiling", "ar_kernel_stats",
-                 "ar_frame_counters"):
+                 "ar_frame_counters", "ar_set_option"):
         getattr(L, name).restype = ctypes.c_int
     _lib = L
     return L
@@ -194,6 +195,10 @@ class Renderer:
         return {names[k].decode(): (int(launches[k]), float(ms[k])) for k in range(N_KERNELS) if names[k]}
 
     def frame_counters(self):
-        out = np.zeros(4, dtype=np.uint32)
+        out = np.zeros(8, dtype=np.uint32)
         self._check(self._L.ar_frame_counters(self._h, out.ctypes.data_as(_u32p)))
-        return {"triangles": int(out[0]), "medium_records": int(out[1]), "large_records": int(out[2])}
+        return {"triangles": int(out[0]), "medium_records": int(out[1]), "large_records": int(out[2]),
+                "bin_records": int(out[3]), "pool_overflow": int(out[4]), "tiled": int(out[5])}
+
+    def set_option(self, name, value):
+        self._check(self._L.ar_set_option(self._h, {"path": 1, "pool_records": 2}[name], int(value)))

@@ -27,10 +27,6 @@
 
 #include "ascii_rast.h"
 
-#ifndef AR_EXP
-#define AR_EXP 0
-#endif
-
 namespace {
 
 constexpr uint64_t kBackgroundKey = (uint64_t(0x3F800000u) << 32) | 0xFFFFFFFFull;  // depth 1.0f
@@ -39,9 +35,9 @@ constexpr int kMediumMaxCells = 4096;   // above this a record goes to the per-c
 constexpr uint32_t kMediumCapacity = 1u << 18;
 constexpr uint32_t kLargeCapacity = 1u << 14;
 
-enum KernelSlot { K_CLEAR = 0, K_RASTER, K_MEDIUM, K_LARGE, K_SHADE, K_ASCII, K_SLOT6, K_SLOT7 };
+enum KernelSlot { K_CLEAR = 0, K_RASTER, K_MEDIUM, K_LARGE, K_SHADE, K_ASCII, K_BIN, K_TILE };
 const char *const kKernelNames[AR_N_KERNELS] = {"k_clear",  "k_raster", "k_raster_medium", "k_raster_large",
-                                                "k_shade", "k_ascii",  "",                ""};
+                                                "k_shade", "k_ascii",  "k_bin",           "k_tile"};
 
 // Everything a frame's kernels need besides the big buffers; passed by value as a kernel argument.
 struct FrameParams {
@@ -56,6 +52,9 @@ struct FrameParams {
     uint32_t n_tris, n_verts;
     int ramp_len, mode_on, mode_radius, mode_thresh;
     int want_ids;    // also store the winning (2*triangle + sub) per cell
+    int ntx, nty;    // tile grid over columns [0, cols) x output rows [ya, yb)
+    uint32_t chunk, n_groups;  // triangles per k_bin workgroup, number of those workgroups
+    uint32_t frame;  // frame counter (selects the binning state block)
     uint8_t ramp[AR_MAX_RAMP];
 };
 
@@ -141,28 +140,48 @@ struct Edges {
     float W[3], Z[3];
 };
 
-// Edge functions of one (sub-)triangle from its clip coordinates.  False when the triangle cannot
-// produce fragments (non-finite or w <= 0 vertex, back face, zero area).  X, Y receive the
-// pixel-homogeneous vertex coordinates for the caller's cell-range computation.
-__device__ __forceinline__ bool edge_setup(const float (&c0)[4], const float (&c1)[4], const float (&c2)[4], float hw,
-                                           float hh, Edges &e, float (&X)[3], float (&Y)[3]) {
+// Pixel-homogeneous vertices of one (sub-)triangle: (X, Y, W) = ((x_c + w_c) cols/2, (y_c + w_c) rows/2, w_c),
+// GL window orientation (y up), plus clip z for the depth interpolation.
+struct Screen {
+    float X[3], Y[3], W[3], Z[3];
+};
+
+// False when the triangle cannot produce fragments because a vertex is non-finite or has w <= 0.
+__device__ __forceinline__ bool to_screen(const float (&c0)[4], const float (&c1)[4], const float (&c2)[4], float hw,
+                                          float hh, Screen &s) {
     bool ok = true;
 #pragma unroll
     for (int q = 0; q < 4; q++) ok = ok && isfinite(c0[q]) && isfinite(c1[q]) && isfinite(c2[q]);
     ok = ok && (c0[3] > 0.0f) && (c1[3] > 0.0f) && (c2[3] > 0.0f);
     if (!ok) return false;
-    e.W[0] = c0[3]; e.W[1] = c1[3]; e.W[2] = c2[3];
-    e.Z[0] = c0[2]; e.Z[1] = c1[2]; e.Z[2] = c2[2];
-    X[0] = (c0[0] + c0[3]) * hw; X[1] = (c1[0] + c1[3]) * hw; X[2] = (c2[0] + c2[3]) * hw;
-    Y[0] = (c0[1] + c0[3]) * hh; Y[1] = (c1[1] + c1[3]) * hh; Y[2] = (c2[1] + c2[3]) * hh;
+    s.W[0] = c0[3]; s.W[1] = c1[3]; s.W[2] = c2[3];
+    s.Z[0] = c0[2]; s.Z[1] = c1[2]; s.Z[2] = c2[2];
+    s.X[0] = (c0[0] + c0[3]) * hw; s.X[1] = (c1[0] + c1[3]) * hw; s.X[2] = (c2[0] + c2[3]) * hw;
+    s.Y[0] = (c0[1] + c0[3]) * hh; s.Y[1] = (c1[1] + c1[3]) * hh; s.Y[2] = (c2[1] + c2[3]) * hh;
+    return true;
+}
+
+// Edge functions e_k = v_{k+1} x v_{k+2} in binary64 (every product of two binary32 values is exact).
+template <typename S>
+__device__ __forceinline__ void edges_from_screen(const S &s, Edges &e) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) {  // e_k = v_{k+1} x v_{k+2}
+    for (int k = 0; k < 3; k++) {
         const int p = (k + 1) % 3, q = (k + 2) % 3;
-        e.a[k] = double(Y[p]) * double(e.W[q]) - double(Y[q]) * double(e.W[p]);
-        e.b[k] = double(X[q]) * double(e.W[p]) - double(X[p]) * double(e.W[q]);
-        e.c[k] = double(X[p]) * double(Y[q]) - double(X[q]) * double(Y[p]);
+        e.a[k] = double(s.Y[p]) * double(s.W[q]) - double(s.Y[q]) * double(s.W[p]);
+        e.b[k] = double(s.X[q]) * double(s.W[p]) - double(s.X[p]) * double(s.W[q]);
+        e.c[k] = double(s.X[p]) * double(s.Y[q]) - double(s.X[q]) * double(s.Y[p]);
+        e.W[k] = s.W[k];
+        e.Z[k] = s.Z[k];
     }
-    const double det = (double(X[0]) * e.a[0] + double(Y[0]) * e.b[0]) + double(e.W[0]) * e.c[0];
+}
+
+// det = v0 . (v1 x v2) > 0: counter-clockwise in the window, i.e. front facing; <= 0 is culled
+// (back face or zero area).
+__device__ __forceinline__ bool front_facing(const Screen &s) {
+    const double a0 = double(s.Y[1]) * double(s.W[2]) - double(s.Y[2]) * double(s.W[1]);
+    const double b0 = double(s.X[2]) * double(s.W[1]) - double(s.X[1]) * double(s.W[2]);
+    const double c0 = double(s.X[1]) * double(s.Y[2]) - double(s.X[2]) * double(s.Y[1]);
+    const double det = (double(s.X[0]) * a0 + double(s.Y[0]) * b0) + double(s.W[0]) * c0;
     return det > 0.0;
 }
 
@@ -231,20 +250,17 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const float *__r
     const uint32_t v0 = idx[3 * size_t(t)], v1 = idx[3 * size_t(t) + 1], v2 = idx[3 * size_t(t) + 2];
     if (v0 >= fp.n_verts || v1 >= fp.n_verts || v2 >= fp.n_verts) return;
     const Vert<0> in0 = load_vertex<0>(fp, vbo, v0), in1 = load_vertex<0>(fp, vbo, v1), in2 = load_vertex<0>(fp, vbo, v2);
-#if AR_EXP == 3
-    if (in0.c[0] + in1.c[1] + in2.c[2] + in0.c[3] + in1.c[3]+ in2.c[0] == 0.123f) vis[0] = t;
-    return;
-#endif
     Vert<0> s0[3], s1[3];
     const int ns = clip_near<0>(in0, in1, in2, s0, s1);
     const int jlo = fp.rows - fp.yb, jhi = fp.rows - 1 - fp.ya;  // window rows of the rendered strip
     for (int s = 0; s < ns; s++) {
         const Vert<0> t0 = s ? s1[0] : s0[0], t1 = s ? s1[1] : s0[1], t2 = s ? s1[2] : s0[2];
-        Edges e;
-        float X[3], Y[3];
-        if (!edge_setup(t0.c, t1.c, t2.c, fp.hw, fp.hh, e, X, Y)) continue;
+        Screen sc;
+        if (!to_screen(t0.c, t1.c, t2.c, fp.hw, fp.hh, sc) || !front_facing(sc)) continue;
         int i0, i1, j0, j1;
-        if (!cell_range(X, Y, e.W, fp.cols, jlo, jhi, i0, i1, j0, j1)) continue;
+        if (!cell_range(sc.X, sc.Y, sc.W, fp.cols, jlo, jhi, i0, i1, j0, j1)) continue;
+        Edges e;
+        edges_from_screen(sc, e);
         const uint32_t id = 2u * t + uint32_t(s);
         const int ncells = (i1 - i0 + 1) * (j1 - j0 + 1);
         if (ncells > kSmallMaxCells) {
@@ -265,19 +281,11 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams fp, const float *__r
             }
             // queue full: fall through and scan the range here (slow but correct)
         }
-#if AR_EXP == 2
-        if (ncells == 12345678) vis[0] = id;
-        continue;
-#endif
         for (int j = j0; j <= j1; j++) {
             const size_t row = size_t(fp.rows - 1 - j) * fp.cols;
             for (int i = i0; i <= i1; i++) {
                 float f[3], zw;
-#if AR_EXP == 1
-                if (cover(e, i, j, f, zw) && zw == 0.123f) vis_min(vis, row + i, make_key(zw, id));
-#else
                 if (cover(e, i, j, f, zw)) vis_min(vis, row + i, make_key(zw, id));
-#endif
             }
         }
     }
@@ -367,6 +375,32 @@ __device__ __forceinline__ void shade(const FrameParams &fp, const float (&v)[9]
     out[3] = 255;
 }
 
+// Colour and depth of cell (i, j) (GL window coordinates) for winner id = 2*triangle + sub: rebuild the
+// (sub-)triangle from the mesh with the varyings, evaluate the same edge expressions as the raster
+// pass (which reproduces its depth bit for bit), interpolate perspective-correctly and shade.
+__device__ __forceinline__ void shade_cell(const FrameParams &fp, const float *__restrict__ vbo,
+                                           const uint32_t *__restrict__ idx, uint32_t id, int i, int j,
+                                           uint8_t (&px)[4], float &zw) {
+    const uint32_t t = id >> 1, sub = id & 1u;
+    const uint32_t v0 = idx[3 * size_t(t)], v1 = idx[3 * size_t(t) + 1], v2 = idx[3 * size_t(t) + 2];
+    const Vert<9> in0 = load_vertex<9>(fp, vbo, v0), in1 = load_vertex<9>(fp, vbo, v1), in2 = load_vertex<9>(fp, vbo, v2);
+    Vert<9> s0[3], s1[3];
+    clip_near<9>(in0, in1, in2, s0, s1);
+    const Vert<9> t0 = sub ? s1[0] : s0[0], t1 = sub ? s1[1] : s0[1], t2 = sub ? s1[2] : s0[2];
+    Screen sc;
+    to_screen(t0.c, t1.c, t2.c, fp.hw, fp.hh, sc);
+    Edges e;
+    edges_from_screen(sc, e);
+    float f[3];
+    cover(e, i, j, f, zw);
+    const float rS = 1.0f / ((f[0] + f[1]) + f[2]);
+    const float b0 = f[0] * rS, b1 = f[1] * rS, b2 = f[2] * rS;
+    float v[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) v[q] = (b0 * t0.v[q] + b1 * t1.v[q]) + b2 * t2.v[q];
+    shade(fp, v, px);
+}
+
 // One lane per cell of output rows [ya, yb): rebuild the winner's setup, interpolate, shade, store.
 // The cell's visibility key is put back to "background" here, so the next frame needs no clear pass;
 // lane 0 of block 0 retires the frame's queue counters (cnt[0..1] live, cnt[2..3] = last frame).
@@ -390,22 +424,7 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__re
     float zw = 1.0f;
     if (key != kBackgroundKey) {
         vis[cell] = kBackgroundKey;
-        const uint32_t id = uint32_t(key), t = id >> 1, sub = id & 1u;
-        const uint32_t v0 = idx[3 * size_t(t)], v1 = idx[3 * size_t(t) + 1], v2 = idx[3 * size_t(t) + 2];
-        const Vert<9> in0 = load_vertex<9>(fp, vbo, v0), in1 = load_vertex<9>(fp, vbo, v1), in2 = load_vertex<9>(fp, vbo, v2);
-        Vert<9> s0[3], s1[3];
-        clip_near<9>(in0, in1, in2, s0, s1);
-        const Vert<9> t0 = sub ? s1[0] : s0[0], t1 = sub ? s1[1] : s0[1], t2 = sub ? s1[2] : s0[2];
-        Edges e;
-        float X[3], Y[3], f[3];
-        edge_setup(t0.c, t1.c, t2.c, fp.hw, fp.hh, e, X, Y);
-        cover(e, i, j, f, zw);  // same expressions as the raster pass: reproduces its f and depth
-        const float rS = 1.0f / ((f[0] + f[1]) + f[2]);
-        const float b0 = f[0] * rS, b1 = f[1] * rS, b2 = f[2] * rS;
-        float v[9];
-#pragma unroll
-        for (int q = 0; q < 9; q++) v[q] = (b0 * t0.v[q] + b1 * t1.v[q]) + b2 * t2.v[q];
-        shade(fp, v, px);
+        shade_cell(fp, vbo, idx, uint32_t(key), i, j, px, zw);
     }
     *reinterpret_cast<uint32_t *>(rgba + cell * 4) =
         uint32_t(px[0]) | (uint32_t(px[1]) << 8) | (uint32_t(px[2]) << 16) | (uint32_t(px[3]) << 24);
@@ -414,6 +433,292 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__re
     const int ri = ramp_index(px[0], px[1], px[2], fp.ramp_len);
     if (fp.mode_on) ridx[cell] = uint8_t(ri);  // input of the smoothing pass
     else if (r >= fp.row0 && r < fp.row1) ascii[cell] = fp.ramp[ri];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tiled path: triangles are binned to 64x32-cell screen tiles, each tile is resolved in LDS.
+//
+//   k_bin   one workgroup per chunk of consecutive triangles.  Pass 1 counts, per tile, the
+//           (sub-)triangles whose cell range touches it (LDS histogram); the workgroup then reserves
+//           one contiguous run of the record pool with a single global atomic, lays its per-tile
+//           groups out in that run (LDS scan), publishes (start, count) per tile in its directory
+//           column, and pass 2 recomputes the setups and writes the 64-byte records.
+//   k_tile  one workgroup per tile: walks the directory row of the tile, rasterises the records into
+//           a 2048-entry LDS key tile with LDS atomic min (small cell ranges: one lane per record;
+//           large ones: all lanes sweep the range), then shades the covered cells and writes the
+//           tile's RGBA / depth / ramp-index rows.  Visibility keys never touch HBM.
+// If the pool cannot hold a workgroup's records that workgroup rasterises straight into the global
+// key buffer instead and raises the frame's overflow flag; k_tile then merges that buffer in.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTileW = 64, kTileH = 32, kTileCells = kTileW * kTileH;
+constexpr int kMaxTiles = 8000;      // LDS histogram of k_bin: 2 x 4 B per tile, under 64 KB
+constexpr int kMaxGroups = 1024;     // k_bin workgroups = directory columns staged in k_tile's LDS
+constexpr int kTileBigMax = 512;     // per-tile list of records swept cooperatively
+constexpr int kTileSmallCells = 64;  // cell-range area (inside the tile) one lane scans itself
+
+struct __align__(16) BinRec {
+    float X[3], Y[3], W[3], Z[3];
+    uint32_t id;              // 2*triangle + sub-triangle
+    uint16_t i0, i1, j0, j1;  // inclusive cell range, GL window rows (y up)
+    uint32_t pad;
+};
+static_assert(sizeof(BinRec) == 64, "bin records are four 16-byte loads");
+
+// Exclusive prefix sum of v over the 256 lanes of the workgroup (lane order); total = sum of all.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s_wave, uint32_t &total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t n = __shfl_up(incl, d);
+        if (lane >= uint32_t(d)) incl += n;
+    }
+    if (lane == 63u) s_wave[wave] = incl;
+    __syncthreads();
+    const uint32_t w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
+    const uint32_t off = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
+    total = w0 + w1 + w2 + w3;
+    __syncthreads();
+    return off + incl - v;
+}
+
+// Calls f(screen, i0, i1, j0, j1, id) for every sub-triangle of triangle t that can produce fragments
+// in window rows [jlo, jhi]: transformed, near-clipped, front facing, with a non-empty cell range.
+template <typename F>
+__device__ __forceinline__ void for_each_subtri(const FrameParams &fp, const float *__restrict__ vbo,
+                                                const uint32_t *__restrict__ idx, uint32_t t, int jlo, int jhi, F &&f) {
+    const uint32_t v0 = idx[3 * size_t(t)], v1 = idx[3 * size_t(t) + 1], v2 = idx[3 * size_t(t) + 2];
+    if (v0 >= fp.n_verts || v1 >= fp.n_verts || v2 >= fp.n_verts) return;
+    const Vert<0> in0 = load_vertex<0>(fp, vbo, v0), in1 = load_vertex<0>(fp, vbo, v1), in2 = load_vertex<0>(fp, vbo, v2);
+    Vert<0> s0[3], s1[3];
+    const int ns = clip_near<0>(in0, in1, in2, s0, s1);
+    for (int s = 0; s < ns; s++) {
+        const Vert<0> t0 = s ? s1[0] : s0[0], t1 = s ? s1[1] : s0[1], t2 = s ? s1[2] : s0[2];
+        Screen sc;
+        if (!to_screen(t0.c, t1.c, t2.c, fp.hw, fp.hh, sc) || !front_facing(sc)) continue;
+        int i0, i1, j0, j1;
+        if (!cell_range(sc.X, sc.Y, sc.W, fp.cols, jlo, jhi, i0, i1, j0, j1)) continue;
+        f(sc, i0, i1, j0, j1, 2u * t + uint32_t(s));
+    }
+}
+
+// state: two blocks of 4 words used by alternate frames: [0] pool cursor (records reserved so far),
+// [1] overflow flag, [2..3] spare.  The block of the NEXT frame is zeroed here.
+__global__ __launch_bounds__(256) void k_bin(FrameParams fp, const float *__restrict__ vbo,
+                                             const uint32_t *__restrict__ idx, BinRec *__restrict__ pool,
+                                             uint32_t pool_cap, uint2 *__restrict__ dir, uint32_t *__restrict__ state,
+                                             uint64_t *__restrict__ vis) {
+    extern __shared__ uint32_t s_hist[];  // count[nt] then start[nt]
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_base, s_direct;
+    const int nt = fp.ntx * fp.nty;
+    uint32_t *count = s_hist, *start = s_hist + nt;
+    const uint32_t tid = threadIdx.x;
+    for (int k = int(tid); k < nt; k += 256) count[k] = 0;
+    uint32_t *st = state + 4 * (fp.frame & 1u), *st_next = state + 4 * ((fp.frame + 1u) & 1u);
+    if (blockIdx.x == 0 && tid == 0) { st_next[0] = 0; st_next[1] = 0; st_next[2] = 0; st_next[3] = 0; }
+    __syncthreads();
+    const uint32_t t_begin = blockIdx.x * fp.chunk;
+    const uint32_t t_end = min(t_begin + fp.chunk, fp.n_tris);
+    const int jlo = fp.rows - fp.yb, jhi = fp.rows - 1 - fp.ya;
+
+    for (uint32_t t = t_begin + tid; t < t_end; t += 256)
+        for_each_subtri(fp, vbo, idx, t, jlo, jhi, [&](const Screen &, int i0, int i1, int j0, int j1, uint32_t) {
+            const int tx0 = i0 >> 6, tx1 = i1 >> 6;
+            const int ty0 = (fp.rows - 1 - j1 - fp.ya) >> 5, ty1 = (fp.rows - 1 - j0 - fp.ya) >> 5;
+            for (int ty = ty0; ty <= ty1; ty++)
+                for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&count[ty * fp.ntx + tx], 1u);
+        });
+    __syncthreads();
+
+    const int per = (nt + 255) / 256;
+    const int kb = min(int(tid) * per, nt), ke = min(kb + per, nt);
+    uint32_t sum = 0;
+    for (int k = kb; k < ke; k++) { start[k] = sum; sum += count[k]; }
+    uint32_t total;
+    const uint32_t off = block_exclusive_scan(sum, s_wave, total);
+    for (int k = kb; k < ke; k++) start[k] += off;
+    if (tid == 0) {
+        uint32_t base = 0, direct = 0;
+        if (total) {
+            base = atomicAdd(&st[0], total);
+            if (base > pool_cap || total > pool_cap - base) { direct = 1; atomicExch(&st[1], 1u); }
+        }
+        s_base = base; s_direct = direct;
+    }
+    __syncthreads();
+    const uint32_t base = s_base;
+    const bool direct = s_direct != 0;
+    for (int k = int(tid); k < nt; k += 256) {
+        dir[size_t(k) * fp.n_groups + blockIdx.x] = direct ? make_uint2(0u, 0u) : make_uint2(base + start[k], count[k]);
+        count[k] = 0;  // becomes the write cursor of pass 2
+    }
+    __syncthreads();
+
+    for (uint32_t t = t_begin + tid; t < t_end; t += 256)
+        for_each_subtri(fp, vbo, idx, t, jlo, jhi, [&](const Screen &sc, int i0, int i1, int j0, int j1, uint32_t id) {
+            if (direct) {  // pool exhausted: resolve through the global key buffer
+                Edges e;
+                edges_from_screen(sc, e);
+                for (int j = j0; j <= j1; j++) {
+                    const size_t row = size_t(fp.rows - 1 - j) * fp.cols;
+                    for (int i = i0; i <= i1; i++) {
+                        float f[3], zw;
+                        if (cover(e, i, j, f, zw)) vis_min(vis, row + i, make_key(zw, id));
+                    }
+                }
+                return;
+            }
+            BinRec r;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { r.X[k] = sc.X[k]; r.Y[k] = sc.Y[k]; r.W[k] = sc.W[k]; r.Z[k] = sc.Z[k]; }
+            r.id = id;
+            r.i0 = uint16_t(i0); r.i1 = uint16_t(i1); r.j0 = uint16_t(j0); r.j1 = uint16_t(j1);
+            r.pad = 0;
+            const int tx0 = i0 >> 6, tx1 = i1 >> 6;
+            const int ty0 = (fp.rows - 1 - j1 - fp.ya) >> 5, ty1 = (fp.rows - 1 - j0 - fp.ya) >> 5;
+            for (int ty = ty0; ty <= ty1; ty++)
+                for (int tx = tx0; tx <= tx1; tx++) {
+                    const int tile = ty * fp.ntx + tx;
+                    const uint32_t slot = atomicAdd(&count[tile], 1u);
+                    pool[size_t(base) + start[tile] + slot] = r;
+                }
+        });
+}
+
+__global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__restrict__ vbo,
+                                              const uint32_t *__restrict__ idx, const BinRec *__restrict__ pool,
+                                              const uint2 *__restrict__ dir, const uint32_t *__restrict__ state,
+                                              uint64_t *__restrict__ vis, uint8_t *__restrict__ rgba,
+                                              float *__restrict__ depth, uint8_t *__restrict__ ascii,
+                                              uint8_t *__restrict__ ridx, uint32_t *__restrict__ ids) {
+    __shared__ uint64_t keys[kTileCells];
+    __shared__ uint32_t seg_start[kMaxGroups], seg_scan[kMaxGroups + 1];
+    __shared__ uint32_t big[kTileBigMax];
+    __shared__ uint16_t covered[kTileCells];
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t n_big, n_cov;
+    const uint32_t tid = threadIdx.x;
+    const int tile = int(blockIdx.x);
+    const int tx0 = (tile % fp.ntx) * kTileW, tr0 = fp.ya + (tile / fp.ntx) * kTileH;  // first column / output row
+    const int tx1 = min(tx0 + kTileW, fp.cols) - 1, tr1 = min(tr0 + kTileH, fp.yb) - 1;  // last column / row
+    for (int c = int(tid); c < kTileCells; c += 256) keys[c] = kBackgroundKey;
+    if (tid == 0) { n_big = 0; n_cov = 0; }
+
+    // directory row of this tile -> segment starts and an exclusive scan of the segment lengths
+    const int ng = int(fp.n_groups);
+    const int per = (ng + 255) / 256;
+    const int kb = min(int(tid) * per, ng), ke = min(kb + per, ng);
+    uint32_t sum = 0;
+    for (int k = kb; k < ke; k++) {
+        const uint2 d = dir[size_t(tile) * fp.n_groups + k];
+        seg_start[k] = d.x;
+        seg_scan[k] = sum;
+        sum += d.y;
+    }
+    uint32_t n_rec;
+    const uint32_t off = block_exclusive_scan(sum, s_wave, n_rec);
+    for (int k = kb; k < ke; k++) seg_scan[k] += off;
+    if (tid == 0) seg_scan[ng] = n_rec;
+    __syncthreads();
+
+    // records with a small cell range inside the tile: one lane each; the others go to the sweep list
+    for (uint32_t r = tid; r < n_rec; r += 256) {
+        int lo = 0, hi = ng;  // seg_scan[lo] <= r < seg_scan[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (seg_scan[mid] <= r) lo = mid; else hi = mid;
+        }
+        const uint32_t at = seg_start[lo] + (r - seg_scan[lo]);
+        const BinRec rec = pool[at];
+        const int i0 = max(int(rec.i0), tx0), i1 = min(int(rec.i1), tx1);
+        const int r0 = max(fp.rows - 1 - int(rec.j1), tr0), r1 = min(fp.rows - 1 - int(rec.j0), tr1);
+        if ((i1 - i0 + 1) * (r1 - r0 + 1) > kTileSmallCells) {
+            const uint32_t slot = atomicAdd(&n_big, 1u);
+            if (slot < uint32_t(kTileBigMax)) { big[slot] = at; continue; }
+            // list full: this lane scans the range itself (slow but correct)
+        }
+        Edges e;
+        edges_from_screen(rec, e);
+        for (int rr = r0; rr <= r1; rr++) {
+            const int j = fp.rows - 1 - rr;
+            for (int i = i0; i <= i1; i++) {
+                float f[3], zw;
+                if (cover(e, i, j, f, zw))
+                    atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
+                              (unsigned long long)make_key(zw, rec.id));
+            }
+        }
+    }
+    __syncthreads();
+
+    // sweep list: all lanes cover one record's cell range, 256 cells per step
+    const uint32_t nb = min(n_big, uint32_t(kTileBigMax));
+    for (uint32_t b = 0; b < nb; b++) {
+        const BinRec rec = pool[big[b]];
+        const int i0 = max(int(rec.i0), tx0), i1 = min(int(rec.i1), tx1);
+        const int r0 = max(fp.rows - 1 - int(rec.j1), tr0), r1 = min(fp.rows - 1 - int(rec.j0), tr1);
+        const int w = i1 - i0 + 1, n = w * (r1 - r0 + 1);
+        Edges e;
+        edges_from_screen(rec, e);
+        for (int k = int(tid); k < n; k += 256) {
+            const int dr = k / w, i = i0 + (k - dr * w), rr = r0 + dr;
+            float f[3], zw;
+            if (cover(e, i, fp.rows - 1 - rr, f, zw))
+                atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
+                          (unsigned long long)make_key(zw, rec.id));
+        }
+    }
+    __syncthreads();
+
+    // records some k_bin workgroup could not store were resolved through the global key buffer
+    if (state[4 * (fp.frame & 1u) + 1] != 0) {
+        for (int c = int(tid); c < kTileCells; c += 256) {
+            const int rr = tr0 + (c >> 6), i = tx0 + (c & 63);
+            if (i > tx1 || rr > tr1) continue;
+            const size_t cell = size_t(rr) * fp.cols + i;
+            const uint64_t g = vis[cell];
+            if (g != kBackgroundKey) {
+                vis[cell] = kBackgroundKey;
+                if (g < keys[c]) keys[c] = g;
+            }
+        }
+        __syncthreads();
+    }
+
+    // compact the covered cells so that shading runs on full wavefronts
+    for (int c = int(tid); c < kTileCells; c += 256)
+        if (keys[c] != kBackgroundKey) covered[atomicAdd(&n_cov, 1u)] = uint16_t(c);
+    __syncthreads();
+    const uint32_t nc = n_cov;
+    for (uint32_t k = tid; k < nc; k += 256) {
+        const int c = int(covered[k]);
+        const int rr = tr0 + (c >> 6), i = tx0 + (c & 63);
+        const uint32_t id = uint32_t(keys[c]);
+        uint8_t px[4];
+        float zw;
+        shade_cell(fp, vbo, idx, id, i, fp.rows - 1 - rr, px, zw);
+        if (fp.want_ids) ids[size_t(rr) * fp.cols + i] = id;
+        keys[c] = (uint64_t(__float_as_uint(zw)) << 32) |
+                  (uint32_t(px[0]) | (uint32_t(px[1]) << 8) | (uint32_t(px[2]) << 16) | (uint32_t(px[3]) << 24));
+    }
+    __syncthreads();
+
+    // the tile's rows: 64 consecutive cells per row segment
+    for (int c = int(tid); c < kTileCells; c += 256) {
+        const int rr = tr0 + (c >> 6), i = tx0 + (c & 63);
+        if (i > tx1 || rr > tr1) continue;
+        const size_t cell = size_t(rr) * fp.cols + i;
+        const uint64_t k = keys[c];
+        const bool bg = k == kBackgroundKey;  // a shaded cell always has depth < 1.0 in the high word
+        const uint32_t col = bg ? 0xFF000000u : uint32_t(k);
+        reinterpret_cast<uint32_t *>(rgba)[cell] = col;
+        depth[cell] = bg ? 1.0f : __uint_as_float(uint32_t(k >> 32));
+        if (fp.want_ids && bg) ids[cell] = 0xFFFFFFFFu;
+        const int ri = ramp_index(int(col & 255u), int((col >> 8) & 255u), int((col >> 16) & 255u), fp.ramp_len);
+        if (fp.mode_on) ridx[cell] = uint8_t(ri);
+        else if (rr >= fp.row0 && rr < fp.row1) ascii[cell] = fp.ramp[ri];
+    }
 }
 
 // ASCII stage without smoothing over an RGBA8 grid: alpha 2..254 is a literal code, otherwise the ramp.
@@ -519,6 +824,16 @@ struct ar_ctx {
     bool vis_clean = false;      // every key of d_vis is "background" (k_shade restores this each frame)
     TriRec *d_medium = nullptr, *d_large = nullptr;
     uint32_t *d_counters = nullptr;  // [0..1] live queue counters, [2..3] those of the last frame
+    // tiled path
+    int path = 0;                    // 0: tiled when the grid allows it, 1: always the direct path
+    uint32_t pool_cap_option = 0;    // 0: sized from the triangle count
+    BinRec *d_pool = nullptr;
+    uint32_t pool_cap = 0;
+    uint2 *d_dir = nullptr;
+    size_t dir_elems = 0;
+    uint32_t *d_state = nullptr;     // 2 x 4 words, see k_bin
+    uint32_t frame = 0;              // tiled frames enqueued so far
+    bool last_tiled = false;
     uint8_t *d_q_rgba = nullptr, *d_q_ascii = nullptr;
     size_t q_cells = 0;
     bool rendered = false;
@@ -634,33 +949,78 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
 
     const size_t strip_cells = size_t(fp.yb - fp.ya) * cols;
     const unsigned cell_blocks = unsigned((strip_cells + 255) / 256);
+    fp.ntx = (cols + kTileW - 1) / kTileW;
+    fp.nty = (fp.yb - fp.ya + kTileH - 1) / kTileH;
+    const size_t nt = size_t(fp.ntx) * fp.nty;
+    const bool tiled = ctx->path == 0 && nt <= size_t(kMaxTiles) && cols <= 65535 && rows <= 65535;
+    if (tiled) {
+        // k_bin workgroups: chunks of >= 2048 consecutive triangles, at most kMaxGroups of them
+        uint32_t chunk = (fp.n_tris + kMaxGroups - 1) / kMaxGroups;
+        chunk = (chunk + 255u) / 256u * 256u;
+        if (chunk < 2048u) chunk = 2048u;
+        fp.chunk = chunk;
+        fp.n_groups = (fp.n_tris + chunk - 1) / chunk;
+        fp.frame = ctx->frame;
+        const uint32_t want_cap = ctx->pool_cap_option ? ctx->pool_cap_option : 2u * fp.n_tris + 65536u;
+        if (!ctx->d_pool || ctx->pool_cap != want_cap) {
+            AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->d_pool);
+            ctx->d_pool = nullptr; ctx->pool_cap = 0;
+            AR_HIP(ctx, hipMalloc(&ctx->d_pool, size_t(want_cap) * sizeof(BinRec)));
+            ctx->pool_cap = want_cap;
+        }
+        const size_t want_dir = nt * fp.n_groups;
+        if (!ctx->d_dir || ctx->dir_elems < want_dir) {
+            AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->d_dir);
+            ctx->d_dir = nullptr; ctx->dir_elems = 0;
+            AR_HIP(ctx, hipMalloc(&ctx->d_dir, want_dir * sizeof(uint2)));
+            ctx->dir_elems = want_dir;
+        }
+    }
     const bool was_clean = ctx->vis_clean;
-    ctx->vis_clean = false;  // stays false if anything below fails: the next frame then clears again
+    ctx->vis_clean = false;  // stays false if anything below fails: the next frame then starts from scratch
     if (!was_clean) {
-        // first frame on these targets (or after a failed one); in steady state k_shade leaves every
-        // key it consumed at "background" and the queue counters at zero
+        // first frame on these targets (or after a failed one).  In steady state every kernel that
+        // consumes a visibility key, a queue counter or a binning state word puts it back to its
+        // idle value, so no per-frame clear is needed.
         AR_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+        AR_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, 8 * sizeof(uint32_t), ctx->stream));
         Stamper s(ctx, K_CLEAR);
         k_clear<<<2048, 256, 0, ctx->stream>>>(ctx->d_vis, 0, size_t(cols) * rows);
     }
-    {
-        Stamper s(ctx, K_RASTER);
-        k_raster<<<(fp.n_tris + 255) / 256, 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_vis, ctx->d_medium,
-                                                                  ctx->d_large, ctx->d_counters);
-    }
-    {
-        Stamper s(ctx, K_MEDIUM);
-        k_raster_medium<<<512, 256, 0, ctx->stream>>>(fp, ctx->d_vis, ctx->d_medium, ctx->d_counters);
-    }
-    {
-        Stamper s(ctx, K_LARGE);
-        dim3 grid((cols + 15) / 16, (fp.yb - fp.ya + 15) / 16);
-        k_raster_large<<<grid, 256, 0, ctx->stream>>>(fp, ctx->d_vis, ctx->d_large, ctx->d_counters);
-    }
-    {
-        Stamper s(ctx, K_SHADE);
-        k_shade<<<cell_blocks, 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_vis, ctx->d_rgba, ctx->d_depth,
-                                                     ctx->d_ascii, ctx->d_ridx, ctx->d_ids, ctx->d_counters);
+    if (tiled) {
+        {
+            Stamper s(ctx, K_BIN);
+            k_bin<<<fp.n_groups, 256, 2 * nt * sizeof(uint32_t), ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_pool, ctx->pool_cap,
+                                                                               ctx->d_dir, ctx->d_state, ctx->d_vis);
+        }
+        {
+            Stamper s(ctx, K_TILE);
+            k_tile<<<unsigned(nt), 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_pool, ctx->d_dir, ctx->d_state, ctx->d_vis,
+                                                         ctx->d_rgba, ctx->d_depth, ctx->d_ascii, ctx->d_ridx, ctx->d_ids);
+        }
+        ctx->frame++;
+    } else {
+        {
+            Stamper s(ctx, K_RASTER);
+            k_raster<<<(fp.n_tris + 255) / 256, 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_vis, ctx->d_medium,
+                                                                      ctx->d_large, ctx->d_counters);
+        }
+        {
+            Stamper s(ctx, K_MEDIUM);
+            k_raster_medium<<<512, 256, 0, ctx->stream>>>(fp, ctx->d_vis, ctx->d_medium, ctx->d_counters);
+        }
+        {
+            Stamper s(ctx, K_LARGE);
+            dim3 grid((cols + 15) / 16, (fp.yb - fp.ya + 15) / 16);
+            k_raster_large<<<grid, 256, 0, ctx->stream>>>(fp, ctx->d_vis, ctx->d_large, ctx->d_counters);
+        }
+        {
+            Stamper s(ctx, K_SHADE);
+            k_shade<<<cell_blocks, 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_vis, ctx->d_rgba, ctx->d_depth,
+                                                         ctx->d_ascii, ctx->d_ridx, ctx->d_ids, ctx->d_counters);
+        }
     }
     if (fp.mode_on == 1) {
         Stamper s(ctx, K_ASCII);
@@ -669,6 +1029,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
     AR_HIP(ctx, hipGetLastError());
     ctx->vis_clean = true;
     ctx->rendered = true;
+    ctx->last_tiled = tiled;
     return 0;
 }
 
@@ -688,7 +1049,9 @@ ar_ctx *ar_create(int device_id) {
               hipMalloc(&ctx->d_medium, size_t(kMediumCapacity) * sizeof(TriRec)) == hipSuccess &&
               hipMalloc(&ctx->d_large, size_t(kLargeCapacity) * sizeof(TriRec)) == hipSuccess &&
               hipMalloc(&ctx->d_counters, 4 * sizeof(uint32_t)) == hipSuccess &&
-              hipMemset(ctx->d_counters, 0, 4 * sizeof(uint32_t)) == hipSuccess;
+              hipMemset(ctx->d_counters, 0, 4 * sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc(&ctx->d_state, 8 * sizeof(uint32_t)) == hipSuccess &&
+              hipMemset(ctx->d_state, 0, 8 * sizeof(uint32_t)) == hipSuccess;
     if (!ok) {
         fail(nullptr, AR_E_HIP, "context setup failed: %s", hipGetErrorString(hipGetLastError()));
         ar_destroy(ctx);
@@ -715,6 +1078,7 @@ void ar_destroy(ar_ctx *ctx) {
     (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx);
     (void)hipFree(ctx->d_medium); (void)hipFree(ctx->d_large); (void)hipFree(ctx->d_counters);
     (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii);
+    (void)hipFree(ctx->d_pool); (void)hipFree(ctx->d_dir); (void)hipFree(ctx->d_state);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -891,17 +1255,38 @@ int ar_kernel_stats(ar_ctx *ctx, const char *names[AR_N_KERNELS], uint32_t launc
     return 0;
 }
 
-int ar_frame_counters(ar_ctx *ctx, uint32_t out[4]) {
+int ar_frame_counters(ar_ctx *ctx, uint32_t out[8]) {
     if (!ctx || !out) return AR_E_ARG;
     AR_HIP(ctx, hipSetDevice(ctx->device));
     AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    uint32_t c[4] = {0, 0, 0, 0};
+    uint32_t c[4] = {0, 0, 0, 0}, st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     AR_HIP(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    AR_HIP(ctx, hipMemcpy(st, ctx->d_state, sizeof st, hipMemcpyDeviceToHost));
+    const uint32_t *last = st + 4 * ((ctx->frame + 1u) & 1u);  // block of the last tiled frame
+    for (int k = 0; k < 8; k++) out[k] = 0;
     out[0] = ctx->n_tris;
-    out[1] = c[2];
-    out[2] = c[3];
-    out[3] = 0;
+    out[1] = ctx->last_tiled ? 0 : c[2];
+    out[2] = ctx->last_tiled ? 0 : c[3];
+    out[3] = ctx->last_tiled ? last[0] : 0;
+    out[4] = ctx->last_tiled ? last[1] : 0;
+    out[5] = ctx->last_tiled ? 1u : 0u;
     return 0;
+}
+
+int ar_set_option(ar_ctx *ctx, int option, long long value) {
+    if (!ctx) return AR_E_ARG;
+    switch (option) {
+        case AR_OPT_PATH:
+            if (value != 0 && value != 1) return fail(ctx, AR_E_ARG, "AR_OPT_PATH takes 0 (tiled) or 1 (direct)");
+            ctx->path = int(value);
+            return 0;
+        case AR_OPT_POOL_RECORDS:
+            if (value < 0 || value > 0x7FFFFFFFll) return fail(ctx, AR_E_ARG, "AR_OPT_POOL_RECORDS out of range");
+            ctx->pool_cap_option = uint32_t(value);
+            return 0;
+        default:
+            return fail(ctx, AR_E_ARG, "unknown option %d", option);
+    }
 }
 
 }  // extern "C"

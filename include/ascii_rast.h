@@ -101,9 +101,21 @@ int ar_quantize(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *a
 int ar_set_profiling(ar_ctx *ctx, int on);
 int ar_kernel_stats(ar_ctx *ctx, const char *names[AR_N_KERNELS], uint32_t launches[AR_N_KERNELS], float total_ms[AR_N_KERNELS]);
 
-/* Counters of the last rendered frame: [0] triangles submitted, [1] records queued for the
- * medium-triangle pass, [2] records queued for the large-triangle pass, [3] reserved. */
-int ar_frame_counters(ar_ctx *ctx, uint32_t out[4]);
+/* Counters of the last rendered frame: [0] triangles submitted; direct path: [1] records queued for
+ * the medium-triangle pass, [2] for the large-triangle pass; tiled path: [3] (triangle, tile) records
+ * binned, [4] 1 when the record pool overflowed (the frame is still correct, but slower), [5] 1 when
+ * the frame took the tiled path; [6..7] reserved. */
+int ar_frame_counters(ar_ctx *ctx, uint32_t out[8]);
+
+/* Tuning / test switches (no counterpart in the reference).
+ *   AR_OPT_PATH          0 (default): tile-binned path whenever the grid has at most 8000 tiles of
+ *                        64x32 cells, else the direct path; 1: always the direct path (every
+ *                        fragment resolved with a 64-bit atomic min in HBM).
+ *   AR_OPT_POOL_RECORDS  capacity of the bin-record pool in 64-byte records; 0 (default) sizes it
+ *                        as 2 x triangles + 65536. */
+#define AR_OPT_PATH 1
+#define AR_OPT_POOL_RECORDS 2
+int ar_set_option(ar_ctx *ctx, int option, long long value);
 
 #ifdef __cplusplus
 }

@@ -12,9 +12,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def R(pkg):
+@pytest.fixture(scope="module", params=["tiled", "direct"])
+def R(pkg, request):
+    """One renderer per resolve path: tile-binned (LDS z-resolve, the default) and direct (global
+    64-bit atomic min).  Every parity test runs on both."""
     r = pkg.Renderer(0)
+    r.set_option("path", 0 if request.param == "tiled" else 1)
+    r.path_name = request.param
     yield r
     r.close()
 
@@ -71,8 +75,10 @@ def test_reference_scenes_from_fixture(pkg, oracle, R, golden_dir):
         sc = {"name": case["scene"] + "/" + case["cam_name"], "vbo": vbo, "idx": idx, "proj": proj, "view": view,
               "lights": pkg.host.pack_lights(scene), "cols": case["cols"], "rows": case["rows"]}
         _check(pkg, oracle, R, sc)
-        seen_large = seen_large or R.frame_counters()["large_records"] > 0
-    assert seen_large                  # the plane quads exercised the large-triangle pass
+        c = R.frame_counters()
+        assert c["tiled"] == (1 if R.path_name == "tiled" else 0)
+        seen_large = seen_large or c["large_records"] > 0 or c["bin_records"] > idx.size // 3
+    assert seen_large                  # the plane quads exercised the large-triangle handling
 
 
 def test_c3_million_triangles_1080p(pkg, oracle, R):
@@ -110,7 +116,41 @@ def test_near_plane_and_huge_triangles(pkg, oracle, R):
         _check(pkg, oracle, R, sc, label="soup %dx%d" % (cols, rows))
         if cols == 200:
             c = R.frame_counters()
-            assert c["medium_records"] > 0 and c["large_records"] > 0
+            if R.path_name == "direct":
+                assert c["medium_records"] > 0 and c["large_records"] > 0
+            else:
+                assert c["bin_records"] > 0 and c["pool_overflow"] == 0
+
+
+def test_pool_overflow_falls_back_and_stays_exact(pkg, oracle):
+    """A record pool far too small for the frame: some binning workgroups must resolve through the
+    global key buffer, and the merged result is still bit-exact - also on the following frames."""
+    r = pkg.Renderer(0)
+    try:
+        sc = pkg.scenes.random_scene(300_000, 640, 360)
+        for cap in (1000, 50_000, 1, 0):
+            r.set_option("pool_records", cap)
+            for _ in range(2):
+                _check(pkg, oracle, r, sc, label="pool %d" % cap)
+            c = r.frame_counters()
+            assert c["tiled"] == 1 and c["pool_overflow"] == (1 if cap else 0), (cap, c)
+        sc2 = pkg.scenes.icosphere_scene(cols=320, rows=200)
+        r.set_option("pool_records", 100)
+        _check(pkg, oracle, r, sc2)
+        assert r.frame_counters()["pool_overflow"] == 1
+    finally:
+        r.close()
+
+
+def test_many_tiles_take_the_direct_path(pkg, oracle):
+    """More than 8000 tiles (here 8192 x 2048 cells = 8192 tiles): the library falls back to the direct path."""
+    r = pkg.Renderer(0)
+    try:
+        sc = pkg.scenes.random_scene(100_000, 8192, 2048)
+        _check(pkg, oracle, r, sc, mode=(False, 2, 12))
+        assert r.frame_counters()["tiled"] == 0
+    finally:
+        r.close()
 
 
 def test_shared_edges_have_exactly_one_owner(pkg, R):
