@@ -438,29 +438,34 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__re
 // ------------------------------------------------------------------------------------------------
 // Tiled path: triangles are binned to 64x32-cell screen tiles, each tile is resolved in LDS.
 //
-//   k_bin   one workgroup per chunk of consecutive triangles.  Pass 1 counts, per tile, the
-//           (sub-)triangles whose cell range touches it (LDS histogram); the workgroup then reserves
-//           one contiguous run of the record pool with a single global atomic, lays its per-tile
-//           groups out in that run (LDS scan), publishes (start, count) per tile in its directory
-//           column, and pass 2 recomputes the setups and writes the 64-byte records.
-//   k_tile  one workgroup per tile: walks the directory row of the tile, rasterises the records into
-//           a 2048-entry LDS key tile with LDS atomic min (small cell ranges: one lane per record;
-//           large ones: all lanes sweep the range), then shades the covered cells and writes the
-//           tile's RGBA / depth / ramp-index rows.  Visibility keys never touch HBM.
-// If the pool cannot hold a workgroup's records that workgroup rasterises straight into the global
+//   k_tripos  (at mesh upload) gathers the three positions of every triangle into nine planes of
+//             n_tris floats, so the per-frame pass reads 36 contiguous bytes per triangle, coalesced,
+//             instead of chasing indices into 36-byte-stride vertices.
+//   k_bin     one workgroup per chunk of consecutive triangles, ONE pass over the positions: every
+//             sub-triangle that can produce fragments gets its 64-byte setup record stored at
+//             records[id] (id = 2*triangle + sub) and is counted into the LDS histogram of the tiles
+//             its cell range touches.  The workgroup then reserves one contiguous run of the index
+//             pool with a single global atomic, lays its per-tile groups out in that run (LDS scan),
+//             publishes (start, count) per tile in its directory column, and writes the ids.
+//   k_tile    one workgroup per tile: walks the directory row of the tile, rasterises the records into
+//             a 2048-entry LDS key tile with LDS atomic min (small cell ranges: one lane per record;
+//             large ones: all lanes sweep the range), then shades the covered cells and writes the
+//             tile's RGBA / depth / ramp-index rows.  Visibility keys never touch HBM.
+// If the index pool cannot hold a workgroup's ids, that workgroup rasterises straight into the global
 // key buffer instead and raises the frame's overflow flag; k_tile then merges that buffer in.
 // ------------------------------------------------------------------------------------------------
 constexpr int kTileW = 64, kTileH = 32, kTileCells = kTileW * kTileH;
-constexpr int kMaxTiles = 8000;      // LDS histogram of k_bin: 2 x 4 B per tile, under 64 KB
-constexpr int kMaxGroups = 1024;     // k_bin workgroups = directory columns staged in k_tile's LDS
-constexpr int kTileBigMax = 512;     // per-tile list of records swept cooperatively
-constexpr int kTileSmallCells = 64;  // cell-range area (inside the tile) one lane scans itself
+constexpr int kMaxTiles = 8000;        // LDS histogram of k_bin: 2 x 4 B per tile, under 64 KB
+constexpr int kMaxGroups = 2048;       // k_bin workgroups = directory columns staged in k_tile's LDS
+constexpr uint32_t kMaxChunk = 16384;  // triangles per k_bin workgroup: 64 per lane (two 64-bit masks)
+constexpr int kTileBigMax = 512;       // per-tile list of records swept cooperatively
+constexpr int kTileSmallCells = 64;    // cell-range area (inside the tile) one lane scans itself
 
 struct __align__(16) BinRec {
     float X[3], Y[3], W[3], Z[3];
     uint32_t id;              // 2*triangle + sub-triangle
     uint16_t i0, i1, j0, j1;  // inclusive cell range, GL window rows (y up)
-    uint32_t pad;
+    uint32_t clipped;         // 1: produced by the near-plane clip (vertices differ from the mesh's)
 };
 static_assert(sizeof(BinRec) == 64, "bin records are four 16-byte loads");
 
@@ -482,31 +487,59 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
     return off + incl - v;
 }
 
-// Calls f(screen, i0, i1, j0, j1, id) for every sub-triangle of triangle t that can produce fragments
-// in window rows [jlo, jhi]: transformed, near-clipped, front facing, with a non-empty cell range.
+// Positions of triangle t's vertices -> planes [k*stride + t], k = 3*vertex + axis.  A triangle that
+// names a vertex outside the buffer gets NaN positions, which every later stage rejects.
+__global__ __launch_bounds__(256) void k_tripos(const float *__restrict__ vbo, const uint32_t *__restrict__ idx,
+                                                uint32_t n_verts, uint32_t n_tris, size_t stride,
+                                                float *__restrict__ tripos) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_tris) return;
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+        const uint32_t vi = idx[3 * size_t(t) + v];
+        const bool ok = vi < n_verts;
+        const float *p = vbo + size_t(ok ? vi : 0u) * 9;
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) tripos[size_t(3 * v + ax) * stride + t] = ok ? p[ax] : __builtin_nanf("");
+    }
+}
+
+__device__ __forceinline__ Vert<0> transform_position(const FrameParams &fp, float x, float y, float z) {
+    Vert<0> o;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        o.c[r] = ((fp.pv[0 * 4 + r] * x + fp.pv[1 * 4 + r] * y) + fp.pv[2 * 4 + r] * z) + fp.pv[3 * 4 + r];
+    return o;
+}
+
+// Calls f(screen, i0, i1, j0, j1, sub, clipped) for every sub-triangle of triangle t that can produce
+// fragments in window rows [jlo, jhi]: transformed, near-clipped, front facing, non-empty cell range.
 template <typename F>
-__device__ __forceinline__ void for_each_subtri(const FrameParams &fp, const float *__restrict__ vbo,
-                                                const uint32_t *__restrict__ idx, uint32_t t, int jlo, int jhi, F &&f) {
-    const uint32_t v0 = idx[3 * size_t(t)], v1 = idx[3 * size_t(t) + 1], v2 = idx[3 * size_t(t) + 2];
-    if (v0 >= fp.n_verts || v1 >= fp.n_verts || v2 >= fp.n_verts) return;
-    const Vert<0> in0 = load_vertex<0>(fp, vbo, v0), in1 = load_vertex<0>(fp, vbo, v1), in2 = load_vertex<0>(fp, vbo, v2);
+__device__ __forceinline__ void for_each_subtri(const FrameParams &fp, const float *__restrict__ tripos, size_t stride,
+                                                uint32_t t, int jlo, int jhi, F &&f) {
+    float p[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) p[k] = tripos[size_t(k) * stride + t];
+    const Vert<0> in0 = transform_position(fp, p[0], p[1], p[2]), in1 = transform_position(fp, p[3], p[4], p[5]),
+                  in2 = transform_position(fp, p[6], p[7], p[8]);
     Vert<0> s0[3], s1[3];
     const int ns = clip_near<0>(in0, in1, in2, s0, s1);
+    const bool clipped = ns == 2 || (in0.c[2] + in0.c[3] < 0.0f) || (in1.c[2] + in1.c[3] < 0.0f) || (in2.c[2] + in2.c[3] < 0.0f);
     for (int s = 0; s < ns; s++) {
         const Vert<0> t0 = s ? s1[0] : s0[0], t1 = s ? s1[1] : s0[1], t2 = s ? s1[2] : s0[2];
         Screen sc;
         if (!to_screen(t0.c, t1.c, t2.c, fp.hw, fp.hh, sc) || !front_facing(sc)) continue;
         int i0, i1, j0, j1;
         if (!cell_range(sc.X, sc.Y, sc.W, fp.cols, jlo, jhi, i0, i1, j0, j1)) continue;
-        f(sc, i0, i1, j0, j1, 2u * t + uint32_t(s));
+        f(sc, i0, i1, j0, j1, s, clipped);
     }
 }
 
-// state: two blocks of 4 words used by alternate frames: [0] pool cursor (records reserved so far),
+// state: two blocks of 4 words used by alternate frames: [0] index-pool cursor (ids reserved so far),
 // [1] overflow flag, [2..3] spare.  The block of the NEXT frame is zeroed here.
-__global__ __launch_bounds__(256) void k_bin(FrameParams fp, const float *__restrict__ vbo,
-                                             const uint32_t *__restrict__ idx, BinRec *__restrict__ pool,
-                                             uint32_t pool_cap, uint2 *__restrict__ dir, uint32_t *__restrict__ state,
+__global__ __launch_bounds__(256) void k_bin(FrameParams fp, const float *__restrict__ tripos, size_t stride,
+                                             BinRec *__restrict__ records, uint32_t *__restrict__ ipool,
+                                             uint32_t ipool_cap, uint2 *__restrict__ dir, uint32_t *__restrict__ state,
                                              uint64_t *__restrict__ vis) {
     extern __shared__ uint32_t s_hist[];  // count[nt] then start[nt]
     __shared__ uint32_t s_wave[4];
@@ -522,8 +555,21 @@ __global__ __launch_bounds__(256) void k_bin(FrameParams fp, const float *__rest
     const uint32_t t_end = min(t_begin + fp.chunk, fp.n_tris);
     const int jlo = fp.rows - fp.yb, jhi = fp.rows - 1 - fp.ya;
 
-    for (uint32_t t = t_begin + tid; t < t_end; t += 256)
-        for_each_subtri(fp, vbo, idx, t, jlo, jhi, [&](const Screen &, int i0, int i1, int j0, int j1, uint32_t) {
+    // pass over the positions: store records, count tiles; mask[s] bit k = sub-triangle s of this
+    // lane's k-th triangle has a record
+    unsigned long long mask[2] = {0ull, 0ull};
+    int k = 0;
+    for (uint32_t t = t_begin + tid; t < t_end; t += 256, k++)
+        for_each_subtri(fp, tripos, stride, t, jlo, jhi,
+                        [&](const Screen &sc, int i0, int i1, int j0, int j1, int sub, bool clipped) {
+            BinRec r;
+#pragma unroll
+            for (int q = 0; q < 3; q++) { r.X[q] = sc.X[q]; r.Y[q] = sc.Y[q]; r.W[q] = sc.W[q]; r.Z[q] = sc.Z[q]; }
+            r.id = 2u * t + uint32_t(sub);
+            r.i0 = uint16_t(i0); r.i1 = uint16_t(i1); r.j0 = uint16_t(j0); r.j1 = uint16_t(j1);
+            r.clipped = clipped ? 1u : 0u;
+            records[r.id] = r;
+            mask[sub] |= 1ull << k;
             const int tx0 = i0 >> 6, tx1 = i1 >> 6;
             const int ty0 = (fp.rows - 1 - j1 - fp.ya) >> 5, ty1 = (fp.rows - 1 - j0 - fp.ya) >> 5;
             for (int ty = ty0; ty <= ty1; ty++)
@@ -534,32 +580,39 @@ __global__ __launch_bounds__(256) void k_bin(FrameParams fp, const float *__rest
     const int per = (nt + 255) / 256;
     const int kb = min(int(tid) * per, nt), ke = min(kb + per, nt);
     uint32_t sum = 0;
-    for (int k = kb; k < ke; k++) { start[k] = sum; sum += count[k]; }
+    for (int q = kb; q < ke; q++) { start[q] = sum; sum += count[q]; }
     uint32_t total;
     const uint32_t off = block_exclusive_scan(sum, s_wave, total);
-    for (int k = kb; k < ke; k++) start[k] += off;
+    for (int q = kb; q < ke; q++) start[q] += off;
     if (tid == 0) {
         uint32_t base = 0, direct = 0;
         if (total) {
             base = atomicAdd(&st[0], total);
-            if (base > pool_cap || total > pool_cap - base) { direct = 1; atomicExch(&st[1], 1u); }
+            if (base > ipool_cap || total > ipool_cap - base) { direct = 1; atomicExch(&st[1], 1u); }
         }
         s_base = base; s_direct = direct;
     }
     __syncthreads();
     const uint32_t base = s_base;
     const bool direct = s_direct != 0;
-    for (int k = int(tid); k < nt; k += 256) {
-        dir[size_t(k) * fp.n_groups + blockIdx.x] = direct ? make_uint2(0u, 0u) : make_uint2(base + start[k], count[k]);
-        count[k] = 0;  // becomes the write cursor of pass 2
+    for (int q = int(tid); q < nt; q += 256) {
+        dir[size_t(q) * fp.n_groups + blockIdx.x] = direct ? make_uint2(0u, 0u) : make_uint2(base + start[q], count[q]);
+        count[q] = 0;  // becomes the write cursor of the id pass
     }
     __syncthreads();
 
-    for (uint32_t t = t_begin + tid; t < t_end; t += 256)
-        for_each_subtri(fp, vbo, idx, t, jlo, jhi, [&](const Screen &sc, int i0, int i1, int j0, int j1, uint32_t id) {
-            if (direct) {  // pool exhausted: resolve through the global key buffer
+    // id pass: this lane's own records (its stores are visible to itself), grouped by tile
+    k = 0;
+    for (uint32_t t = t_begin + tid; t < t_end; t += 256, k++) {
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++) {
+            if (!((mask[sub] >> k) & 1ull)) continue;
+            const uint32_t id = 2u * t + uint32_t(sub);
+            const BinRec &r = records[id];
+            const int i0 = r.i0, i1 = r.i1, j0 = r.j0, j1 = r.j1;
+            if (direct) {  // index pool exhausted: resolve through the global key buffer
                 Edges e;
-                edges_from_screen(sc, e);
+                edges_from_screen(r, e);
                 for (int j = j0; j <= j1; j++) {
                     const size_t row = size_t(fp.rows - 1 - j) * fp.cols;
                     for (int i = i0; i <= i1; i++) {
@@ -567,31 +620,47 @@ __global__ __launch_bounds__(256) void k_bin(FrameParams fp, const float *__rest
                         if (cover(e, i, j, f, zw)) vis_min(vis, row + i, make_key(zw, id));
                     }
                 }
-                return;
+                continue;
             }
-            BinRec r;
-#pragma unroll
-            for (int k = 0; k < 3; k++) { r.X[k] = sc.X[k]; r.Y[k] = sc.Y[k]; r.W[k] = sc.W[k]; r.Z[k] = sc.Z[k]; }
-            r.id = id;
-            r.i0 = uint16_t(i0); r.i1 = uint16_t(i1); r.j0 = uint16_t(j0); r.j1 = uint16_t(j1);
-            r.pad = 0;
             const int tx0 = i0 >> 6, tx1 = i1 >> 6;
             const int ty0 = (fp.rows - 1 - j1 - fp.ya) >> 5, ty1 = (fp.rows - 1 - j0 - fp.ya) >> 5;
             for (int ty = ty0; ty <= ty1; ty++)
                 for (int tx = tx0; tx <= tx1; tx++) {
                     const int tile = ty * fp.ntx + tx;
-                    const uint32_t slot = atomicAdd(&count[tile], 1u);
-                    pool[size_t(base) + start[tile] + slot] = r;
+                    ipool[size_t(base) + start[tile] + atomicAdd(&count[tile], 1u)] = id;
                 }
-        });
+        }
+    }
+}
+
+// Colour and depth of cell (i, j) from the winner's setup record; unclipped records take their
+// varyings straight from the mesh, clipped ones are rebuilt by shade_cell.
+__device__ __forceinline__ void shade_from_record(const FrameParams &fp, const float *__restrict__ vbo,
+                                                  const uint32_t *__restrict__ idx, const BinRec &rec, int i, int j,
+                                                  uint8_t (&px)[4], float &zw) {
+    if (rec.clipped) { shade_cell(fp, vbo, idx, rec.id, i, j, px, zw); return; }
+    const uint32_t t = rec.id >> 1;
+    const float *a0 = vbo + size_t(idx[3 * size_t(t)]) * 9, *a1 = vbo + size_t(idx[3 * size_t(t) + 1]) * 9,
+                *a2 = vbo + size_t(idx[3 * size_t(t) + 2]) * 9;
+    Edges e;
+    edges_from_screen(rec, e);
+    float f[3];
+    cover(e, i, j, f, zw);
+    const float rS = 1.0f / ((f[0] + f[1]) + f[2]);
+    const float b0 = f[0] * rS, b1 = f[1] * rS, b2 = f[2] * rS;
+    float v[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++) v[q] = (b0 * a0[q] + b1 * a1[q]) + b2 * a2[q];
+    shade(fp, v, px);
 }
 
 __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__restrict__ vbo,
-                                              const uint32_t *__restrict__ idx, const BinRec *__restrict__ pool,
-                                              const uint2 *__restrict__ dir, const uint32_t *__restrict__ state,
-                                              uint64_t *__restrict__ vis, uint8_t *__restrict__ rgba,
-                                              float *__restrict__ depth, uint8_t *__restrict__ ascii,
-                                              uint8_t *__restrict__ ridx, uint32_t *__restrict__ ids) {
+                                              const uint32_t *__restrict__ idx, const BinRec *__restrict__ records,
+                                              const uint32_t *__restrict__ ipool, const uint2 *__restrict__ dir,
+                                              const uint32_t *__restrict__ state, uint64_t *__restrict__ vis,
+                                              uint8_t *__restrict__ rgba, float *__restrict__ depth,
+                                              uint8_t *__restrict__ ascii, uint8_t *__restrict__ ridx,
+                                              uint32_t *__restrict__ ids) {
     __shared__ uint64_t keys[kTileCells];
     __shared__ uint32_t seg_start[kMaxGroups], seg_scan[kMaxGroups + 1];
     __shared__ uint32_t big[kTileBigMax];
@@ -629,13 +698,13 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
             const int mid = (lo + hi) >> 1;
             if (seg_scan[mid] <= r) lo = mid; else hi = mid;
         }
-        const uint32_t at = seg_start[lo] + (r - seg_scan[lo]);
-        const BinRec rec = pool[at];
+        const uint32_t id = ipool[size_t(seg_start[lo]) + (r - seg_scan[lo])];
+        const BinRec rec = records[id];
         const int i0 = max(int(rec.i0), tx0), i1 = min(int(rec.i1), tx1);
         const int r0 = max(fp.rows - 1 - int(rec.j1), tr0), r1 = min(fp.rows - 1 - int(rec.j0), tr1);
         if ((i1 - i0 + 1) * (r1 - r0 + 1) > kTileSmallCells) {
             const uint32_t slot = atomicAdd(&n_big, 1u);
-            if (slot < uint32_t(kTileBigMax)) { big[slot] = at; continue; }
+            if (slot < uint32_t(kTileBigMax)) { big[slot] = id; continue; }
             // list full: this lane scans the range itself (slow but correct)
         }
         Edges e;
@@ -646,7 +715,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
                 float f[3], zw;
                 if (cover(e, i, j, f, zw))
                     atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
-                              (unsigned long long)make_key(zw, rec.id));
+                              (unsigned long long)make_key(zw, id));
             }
         }
     }
@@ -655,7 +724,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
     // sweep list: all lanes cover one record's cell range, 256 cells per step
     const uint32_t nb = min(n_big, uint32_t(kTileBigMax));
     for (uint32_t b = 0; b < nb; b++) {
-        const BinRec rec = pool[big[b]];
+        const BinRec rec = records[big[b]];
         const int i0 = max(int(rec.i0), tx0), i1 = min(int(rec.i1), tx1);
         const int r0 = max(fp.rows - 1 - int(rec.j1), tr0), r1 = min(fp.rows - 1 - int(rec.j0), tr1);
         const int w = i1 - i0 + 1, n = w * (r1 - r0 + 1);
@@ -671,7 +740,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
     }
     __syncthreads();
 
-    // records some k_bin workgroup could not store were resolved through the global key buffer
+    // ids some k_bin workgroup could not store were resolved through the global key buffer
     if (state[4 * (fp.frame & 1u) + 1] != 0) {
         for (int c = int(tid); c < kTileCells; c += 256) {
             const int rr = tr0 + (c >> 6), i = tx0 + (c & 63);
@@ -697,7 +766,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
         const uint32_t id = uint32_t(keys[c]);
         uint8_t px[4];
         float zw;
-        shade_cell(fp, vbo, idx, id, i, fp.rows - 1 - rr, px, zw);
+        shade_from_record(fp, vbo, idx, records[id], i, fp.rows - 1 - rr, px, zw);
         if (fp.want_ids) ids[size_t(rr) * fp.cols + i] = id;
         keys[c] = (uint64_t(__float_as_uint(zw)) << 32) |
                   (uint32_t(px[0]) | (uint32_t(px[1]) << 8) | (uint32_t(px[2]) << 16) | (uint32_t(px[3]) << 24));
@@ -827,7 +896,10 @@ struct ar_ctx {
     // tiled path
     int path = 0;                    // 0: tiled when the grid allows it, 1: always the direct path
     uint32_t pool_cap_option = 0;    // 0: sized from the triangle count
-    BinRec *d_pool = nullptr;
+    float *d_tripos = nullptr;       // 9 planes x tripos_stride floats: triangle positions
+    size_t tripos_stride = 0;
+    BinRec *d_records = nullptr;     // 2 x n_tris setup records, indexed by id
+    uint32_t *d_pool = nullptr;      // ids grouped by (k_bin workgroup, tile)
     uint32_t pool_cap = 0;
     uint2 *d_dir = nullptr;
     size_t dir_elems = 0;
@@ -952,7 +1024,8 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
     fp.ntx = (cols + kTileW - 1) / kTileW;
     fp.nty = (fp.yb - fp.ya + kTileH - 1) / kTileH;
     const size_t nt = size_t(fp.ntx) * fp.nty;
-    const bool tiled = ctx->path == 0 && nt <= size_t(kMaxTiles) && cols <= 65535 && rows <= 65535;
+    const bool tiled = ctx->path == 0 && nt <= size_t(kMaxTiles) && cols <= 65535 && rows <= 65535 && ctx->d_tripos &&
+                       (fp.n_tris + kMaxGroups - 1) / kMaxGroups <= kMaxChunk;
     if (tiled) {
         // k_bin workgroups: chunks of >= 2048 consecutive triangles, at most kMaxGroups of them
         uint32_t chunk = (fp.n_tris + kMaxGroups - 1) / kMaxGroups;
@@ -966,7 +1039,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
             AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
             (void)hipFree(ctx->d_pool);
             ctx->d_pool = nullptr; ctx->pool_cap = 0;
-            AR_HIP(ctx, hipMalloc(&ctx->d_pool, size_t(want_cap) * sizeof(BinRec)));
+            AR_HIP(ctx, hipMalloc(&ctx->d_pool, size_t(want_cap) * sizeof(uint32_t)));
             ctx->pool_cap = want_cap;
         }
         const size_t want_dir = nt * fp.n_groups;
@@ -992,13 +1065,15 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
     if (tiled) {
         {
             Stamper s(ctx, K_BIN);
-            k_bin<<<fp.n_groups, 256, 2 * nt * sizeof(uint32_t), ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_pool, ctx->pool_cap,
-                                                                               ctx->d_dir, ctx->d_state, ctx->d_vis);
+            k_bin<<<fp.n_groups, 256, 2 * nt * sizeof(uint32_t), ctx->stream>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_records,
+                                                                               ctx->d_pool, ctx->pool_cap, ctx->d_dir, ctx->d_state,
+                                                                               ctx->d_vis);
         }
         {
             Stamper s(ctx, K_TILE);
-            k_tile<<<unsigned(nt), 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_pool, ctx->d_dir, ctx->d_state, ctx->d_vis,
-                                                         ctx->d_rgba, ctx->d_depth, ctx->d_ascii, ctx->d_ridx, ctx->d_ids);
+            k_tile<<<unsigned(nt), 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_records, ctx->d_pool, ctx->d_dir,
+                                                         ctx->d_state, ctx->d_vis, ctx->d_rgba, ctx->d_depth, ctx->d_ascii,
+                                                         ctx->d_ridx, ctx->d_ids);
         }
         ctx->frame++;
     } else {
@@ -1079,6 +1154,7 @@ void ar_destroy(ar_ctx *ctx) {
     (void)hipFree(ctx->d_medium); (void)hipFree(ctx->d_large); (void)hipFree(ctx->d_counters);
     (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii);
     (void)hipFree(ctx->d_pool); (void)hipFree(ctx->d_dir); (void)hipFree(ctx->d_state);
+    (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_records);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1091,13 +1167,21 @@ int ar_set_mesh(ar_ctx *ctx, const float *vbo9, uint32_t n_verts, const uint32_t
     if (n_tris && (!vbo9 || !idx || !n_verts)) return fail(ctx, AR_E_ARG, "ar_set_mesh: null buffer with %u triangles", n_tris);
     AR_HIP(ctx, hipSetDevice(ctx->device));
     AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx);
-    ctx->d_vbo = nullptr; ctx->d_idx = nullptr; ctx->n_verts = 0; ctx->n_tris = 0;
+    (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_records);
+    ctx->d_vbo = nullptr; ctx->d_idx = nullptr; ctx->d_tripos = nullptr; ctx->d_records = nullptr;
+    ctx->n_verts = 0; ctx->n_tris = 0;
     if (!n_tris) return 0;
     AR_HIP(ctx, hipMalloc(&ctx->d_vbo, size_t(n_verts) * 9 * sizeof(float)));
     AR_HIP(ctx, hipMalloc(&ctx->d_idx, size_t(n_tris) * 3 * sizeof(uint32_t)));
     AR_HIP(ctx, hipMemcpy(ctx->d_vbo, vbo9, size_t(n_verts) * 9 * sizeof(float), hipMemcpyHostToDevice));
     AR_HIP(ctx, hipMemcpy(ctx->d_idx, idx, size_t(n_tris) * 3 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // derived, position-only stream for the binning pass and the per-id record store of the tiled path
+    ctx->tripos_stride = (size_t(n_tris) + 63) / 64 * 64;
+    AR_HIP(ctx, hipMalloc(&ctx->d_tripos, 9 * ctx->tripos_stride * sizeof(float)));
+    AR_HIP(ctx, hipMalloc(&ctx->d_records, 2 * size_t(n_tris) * sizeof(BinRec)));
+    k_tripos<<<(n_tris + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_vbo, ctx->d_idx, n_verts, n_tris, ctx->tripos_stride, ctx->d_tripos);
+    AR_HIP(ctx, hipGetLastError());
+    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_verts = n_verts; ctx->n_tris = n_tris;
     return 0;
 }

@@ -111,8 +111,8 @@ int ar_frame_counters(ar_ctx *ctx, uint32_t out[8]);
  *   AR_OPT_PATH          0 (default): tile-binned path whenever the grid has at most 8000 tiles of
  *                        64x32 cells, else the direct path; 1: always the direct path (every
  *                        fragment resolved with a 64-bit atomic min in HBM).
- *   AR_OPT_POOL_RECORDS  capacity of the bin-record pool in 64-byte records; 0 (default) sizes it
- *                        as 2 x triangles + 65536. */
+ *   AR_OPT_POOL_RECORDS  capacity of the tiled path's (triangle, tile) index pool in entries;
+ *                        0 (default) sizes it as 2 x triangles + 65536. */
 #define AR_OPT_PATH 1
 #define AR_OPT_POOL_RECORDS 2
 int ar_set_option(ar_ctx *ctx, int option, long long value);
