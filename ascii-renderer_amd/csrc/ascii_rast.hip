@@ -35,9 +35,10 @@ constexpr int kMediumMaxCells = 4096;   // above this a record goes to the per-c
 constexpr uint32_t kMediumCapacity = 1u << 18;
 constexpr uint32_t kLargeCapacity = 1u << 14;
 
-enum KernelSlot { K_CLEAR = 0, K_RASTER, K_MEDIUM, K_LARGE, K_SHADE, K_ASCII, K_BIN, K_TILE };
+enum KernelSlot { K_CLEAR = 0, K_RASTER, K_MEDIUM, K_LARGE, K_SHADE, K_ASCII, K_SETUP, K_FILL, K_TILE };
 const char *const kKernelNames[AR_N_KERNELS] = {"k_clear",  "k_raster", "k_raster_medium", "k_raster_large",
-                                                "k_shade", "k_ascii",  "k_bin",           "k_tile"};
+                                                "k_shade", "k_ascii",  "k_setup",         "k_fill",
+                                                "k_tile"};
 
 // Everything a frame's kernels need besides the big buffers; passed by value as a kernel argument.
 struct FrameParams {
@@ -53,7 +54,8 @@ struct FrameParams {
     int ramp_len, mode_on, mode_radius, mode_thresh;
     int want_ids;    // also store the winning (2*triangle + sub) per cell
     int ntx, nty;    // tile grid over columns [0, cols) x output rows [ya, yb)
-    uint32_t chunk, n_groups;  // triangles per k_bin workgroup, number of those workgroups
+    int nbx, nby;    // bin grid (4x4 tiles per bin)
+    uint32_t chunk, n_groups;  // triangles per k_setup workgroup, number of those workgroups
     uint32_t frame;  // frame counter (selects the binning state block)
     uint8_t ramp[AR_MAX_RAMP];
 };
@@ -436,30 +438,37 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__re
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tiled path: triangles are binned to 64x32-cell screen tiles, each tile is resolved in LDS.
+// Tiled path: sub-triangles are binned to screen bins of 4x4 tiles, each 64x32-cell tile is
+// resolved in LDS.
 //
-//   k_tripos  (at mesh upload) gathers the three positions of every triangle into nine planes of
-//             n_tris floats, so the per-frame pass reads 36 contiguous bytes per triangle, coalesced,
-//             instead of chasing indices into 36-byte-stride vertices.
-//   k_bin     one workgroup per chunk of consecutive triangles, ONE pass over the positions: every
-//             sub-triangle that can produce fragments gets its 64-byte setup record stored at
-//             records[id] (id = 2*triangle + sub) and is counted into the LDS histogram of the tiles
-//             its cell range touches.  The workgroup then reserves one contiguous run of the index
-//             pool with a single global atomic, lays its per-tile groups out in that run (LDS scan),
-//             publishes (start, count) per tile in its directory column, and writes the ids.
-//   k_tile    one workgroup per tile: walks the directory row of the tile, rasterises the records into
-//             a 2048-entry LDS key tile with LDS atomic min (small cell ranges: one lane per record;
-//             large ones: all lanes sweep the range), then shades the covered cells and writes the
-//             tile's RGBA / depth / ramp-index rows.  Visibility keys never touch HBM.
-// If the index pool cannot hold a workgroup's ids, that workgroup rasterises straight into the global
-// key buffer instead and raises the frame's overflow flag; k_tile then merges that buffer in.
+//   k_tristream (at mesh upload) gathers, per triangle, the three positions into nine planes of
+//             n_tris floats (36 contiguous, coalesced bytes per triangle for the per-frame pass) and
+//             the three vertices' 9 varyings into one 108-byte row (one gather per shaded cell
+//             instead of index -> vertex chasing).
+//   k_setup   one pass over the positions, one lane per triangle slot: transform, near clip, cull,
+//             cell range.  Every sub-triangle that can produce fragments gets its 64-byte setup
+//             record at records[id] (id = 2*triangle + sub), its id appended to the workgroup's
+//             survivor list, and is counted into the workgroup's LDS histogram over bins, which is
+//             then published (one row of the count table, one global atomic per non-empty bin).
+//   k_fill    exclusive scan of the bin totals -> start of each bin's entry array; every workgroup
+//             reserves its share of each bin with one returning atomic and writes one entry
+//             (id, 16-bit mask of the bin's tiles the cell range touches) per (survivor, bin).
+//   k_tile    one workgroup per tile: filters its bin's entries by mask bit into an LDS work list,
+//             rasterises those records into a 2048-entry LDS key tile with LDS atomic min (small
+//             cell ranges: one lane per record; large ones: all lanes sweep the range), then shades
+//             the covered cells and writes the tile's RGBA / depth / ramp-index rows.  Visibility
+//             keys never touch HBM.
+// If the entry pool cannot hold a bin, the sub-triangles touching that bin are rasterised straight
+// into the global key buffer by k_fill, which raises the frame's overflow flag; k_tile then merges
+// that buffer in.
 // ------------------------------------------------------------------------------------------------
 constexpr int kTileW = 64, kTileH = 32, kTileCells = kTileW * kTileH;
-constexpr int kMaxTiles = 8000;        // LDS histogram of k_bin: 2 x 4 B per tile, under 64 KB
-constexpr int kMaxGroups = 2048;       // k_bin workgroups = directory columns staged in k_tile's LDS
-constexpr uint32_t kMaxChunk = 16384;  // triangles per k_bin workgroup: 64 per lane (two 64-bit masks)
-constexpr int kTileBigMax = 512;       // per-tile list of records swept cooperatively
-constexpr int kTileSmallCells = 64;    // cell-range area (inside the tile) one lane scans itself
+constexpr int kMaxTiles = 8000;       // tiles per frame the tiled path accepts
+constexpr int kMaxBins = 512;         // bins of 4x4 tiles (8000 / 16 rounded up)
+constexpr int kSetupThreads = 1024;   // k_setup / k_fill workgroup size
+constexpr int kTileBigMax = 512;      // per-tile list of records swept cooperatively
+constexpr int kTileSmallCells = 64;   // cell-range area (inside the tile) one lane scans itself
+constexpr int kTileListMax = 2048;    // ids staged in LDS between the filter and the raster step
 
 struct __align__(16) BinRec {
     float X[3], Y[3], W[3], Z[3];
@@ -469,7 +478,20 @@ struct __align__(16) BinRec {
 };
 static_assert(sizeof(BinRec) == 64, "bin records are four 16-byte loads");
 
-// Exclusive prefix sum of v over the 256 lanes of the workgroup (lane order); total = sum of all.
+// Per-frame binning state, double-buffered by frame parity so that the kernels of frame f can zero
+// the block frame f+1 will use: total[b] entries of bin b, cursor[b] entries already reserved.
+struct BinState {
+    uint32_t total[kMaxBins];
+    uint32_t cursor[kMaxBins];
+    uint32_t start[kMaxBins];   // exclusive scan of total (written by k_fill's first workgroup)
+    uint32_t overflow;          // some bin did not fit the entry pool
+    uint32_t n_entries;         // sum of total
+    uint32_t pad[2];
+};
+
+// Exclusive prefix sum of v over the lanes of the workgroup (lane order); total = sum of all.
+// NW = wavefronts per workgroup.
+template <int NW>
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s_wave, uint32_t &total) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t incl = v;
@@ -480,18 +502,24 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
     }
     if (lane == 63u) s_wave[wave] = incl;
     __syncthreads();
-    const uint32_t w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
-    const uint32_t off = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
-    total = w0 + w1 + w2 + w3;
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const uint32_t x = s_wave[w];
+        if (uint32_t(w) < wave) off += x;
+        tot += x;
+    }
+    total = tot;
     __syncthreads();
     return off + incl - v;
 }
 
-// Positions of triangle t's vertices -> planes [k*stride + t], k = 3*vertex + axis.  A triangle that
-// names a vertex outside the buffer gets NaN positions, which every later stage rejects.
-__global__ __launch_bounds__(256) void k_tripos(const float *__restrict__ vbo, const uint32_t *__restrict__ idx,
-                                                uint32_t n_verts, uint32_t n_tris, size_t stride,
-                                                float *__restrict__ tripos) {
+// Per triangle: positions -> planes pos[k*stride + t] (k = 3*vertex + axis) and the 27 varyings of
+// its vertices -> attr[t*27 ..].  A triangle that names a vertex outside the buffer gets NaN
+// positions, which every later stage rejects.
+__global__ __launch_bounds__(256) void k_tristream(const float *__restrict__ vbo, const uint32_t *__restrict__ idx,
+                                                   uint32_t n_verts, uint32_t n_tris, size_t stride,
+                                                   float *__restrict__ pos, float *__restrict__ attr) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n_tris) return;
 #pragma unroll
@@ -500,7 +528,9 @@ __global__ __launch_bounds__(256) void k_tripos(const float *__restrict__ vbo, c
         const bool ok = vi < n_verts;
         const float *p = vbo + size_t(ok ? vi : 0u) * 9;
 #pragma unroll
-        for (int ax = 0; ax < 3; ax++) tripos[size_t(3 * v + ax) * stride + t] = ok ? p[ax] : __builtin_nanf("");
+        for (int ax = 0; ax < 3; ax++) pos[size_t(3 * v + ax) * stride + t] = ok ? p[ax] : __builtin_nanf("");
+#pragma unroll
+        for (int q = 0; q < 9; q++) attr[size_t(t) * 27 + 9 * v + q] = ok ? p[q] : 0.0f;
     }
 }
 
@@ -535,31 +565,35 @@ __device__ __forceinline__ void for_each_subtri(const FrameParams &fp, const flo
     }
 }
 
-// state: two blocks of 4 words used by alternate frames: [0] index-pool cursor (ids reserved so far),
-// [1] overflow flag, [2..3] spare.  The block of the NEXT frame is zeroed here.
-__global__ __launch_bounds__(256) void k_bin(FrameParams fp, const float *__restrict__ tripos, size_t stride,
-                                             BinRec *__restrict__ records, uint32_t *__restrict__ ipool,
-                                             uint32_t ipool_cap, uint2 *__restrict__ dir, uint32_t *__restrict__ state,
-                                             uint64_t *__restrict__ vis) {
-    extern __shared__ uint32_t s_hist[];  // count[nt] then start[nt]
-    __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_base, s_direct;
-    const int nt = fp.ntx * fp.nty;
-    uint32_t *count = s_hist, *start = s_hist + nt;
+// Range of bins (4x4 tiles = 256x128 cells) a cell range touches.
+__device__ __forceinline__ void bin_range(const FrameParams &fp, int i0, int i1, int j0, int j1, int &bx0, int &bx1,
+                                          int &by0, int &by1) {
+    bx0 = i0 >> 8; bx1 = i1 >> 8;
+    by0 = (fp.rows - 1 - j1 - fp.ya) >> 7; by1 = (fp.rows - 1 - j0 - fp.ya) >> 7;
+}
+
+__global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const float *__restrict__ tripos, size_t stride,
+                                                         BinRec *__restrict__ records, uint32_t *__restrict__ surv,
+                                                         uint32_t *__restrict__ surv_count, uint32_t *__restrict__ dircount,
+                                                         BinState *__restrict__ state) {
+    __shared__ uint32_t hist[kMaxBins];
+    __shared__ uint32_t n_surv;
     const uint32_t tid = threadIdx.x;
-    for (int k = int(tid); k < nt; k += 256) count[k] = 0;
-    uint32_t *st = state + 4 * (fp.frame & 1u), *st_next = state + 4 * ((fp.frame + 1u) & 1u);
-    if (blockIdx.x == 0 && tid == 0) { st_next[0] = 0; st_next[1] = 0; st_next[2] = 0; st_next[3] = 0; }
+    const int nbins = fp.nbx * fp.nby;
+    for (int k = int(tid); k < nbins; k += kSetupThreads) hist[k] = 0;
+    if (tid == 0) n_surv = 0;
+    BinState &st = state[fp.frame & 1u], &st_next = state[(fp.frame + 1u) & 1u];
+    if (blockIdx.x == 0) {  // idle values for the next frame
+        for (int k = int(tid); k < kMaxBins; k += kSetupThreads) { st_next.total[k] = 0; st_next.cursor[k] = 0; }
+        if (tid == 0) { st_next.overflow = 0; st_next.n_entries = 0; }
+    }
     __syncthreads();
     const uint32_t t_begin = blockIdx.x * fp.chunk;
     const uint32_t t_end = min(t_begin + fp.chunk, fp.n_tris);
     const int jlo = fp.rows - fp.yb, jhi = fp.rows - 1 - fp.ya;
+    uint32_t *my_surv = surv + size_t(blockIdx.x) * 2 * fp.chunk;
 
-    // pass over the positions: store records, count tiles; mask[s] bit k = sub-triangle s of this
-    // lane's k-th triangle has a record
-    unsigned long long mask[2] = {0ull, 0ull};
-    int k = 0;
-    for (uint32_t t = t_begin + tid; t < t_end; t += 256, k++)
+    for (uint32_t t = t_begin + tid; t < t_end; t += kSetupThreads)
         for_each_subtri(fp, tripos, stride, t, jlo, jhi,
                         [&](const Screen &sc, int i0, int i1, int j0, int j1, int sub, bool clipped) {
             BinRec r;
@@ -569,79 +603,95 @@ __global__ __launch_bounds__(256) void k_bin(FrameParams fp, const float *__rest
             r.i0 = uint16_t(i0); r.i1 = uint16_t(i1); r.j0 = uint16_t(j0); r.j1 = uint16_t(j1);
             r.clipped = clipped ? 1u : 0u;
             records[r.id] = r;
-            mask[sub] |= 1ull << k;
-            const int tx0 = i0 >> 6, tx1 = i1 >> 6;
-            const int ty0 = (fp.rows - 1 - j1 - fp.ya) >> 5, ty1 = (fp.rows - 1 - j0 - fp.ya) >> 5;
-            for (int ty = ty0; ty <= ty1; ty++)
-                for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&count[ty * fp.ntx + tx], 1u);
+            my_surv[atomicAdd(&n_surv, 1u)] = r.id;
+            int bx0, bx1, by0, by1;
+            bin_range(fp, i0, i1, j0, j1, bx0, bx1, by0, by1);
+            for (int by = by0; by <= by1; by++)
+                for (int bx = bx0; bx <= bx1; bx++) atomicAdd(&hist[by * fp.nbx + bx], 1u);
         });
     __syncthreads();
+    for (int k = int(tid); k < nbins; k += kSetupThreads) {
+        const uint32_t c = hist[k];
+        dircount[size_t(blockIdx.x) * nbins + k] = c;
+        if (c) atomicAdd(&st.total[k], c);
+    }
+    if (tid == 0) surv_count[blockIdx.x] = n_surv;
+}
 
-    const int per = (nt + 255) / 256;
-    const int kb = min(int(tid) * per, nt), ke = min(kb + per, nt);
-    uint32_t sum = 0;
-    for (int q = kb; q < ke; q++) { start[q] = sum; sum += count[q]; }
-    uint32_t total;
-    const uint32_t off = block_exclusive_scan(sum, s_wave, total);
-    for (int q = kb; q < ke; q++) start[q] += off;
-    if (tid == 0) {
-        uint32_t base = 0, direct = 0;
-        if (total) {
-            base = atomicAdd(&st[0], total);
-            if (base > ipool_cap || total > ipool_cap - base) { direct = 1; atomicExch(&st[1], 1u); }
+__global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const BinRec *__restrict__ records,
+                                                        const uint32_t *__restrict__ surv,
+                                                        const uint32_t *__restrict__ surv_count,
+                                                        const uint32_t *__restrict__ dircount, BinState *__restrict__ state,
+                                                        unsigned long long *__restrict__ entries, uint32_t entries_cap,
+                                                        uint64_t *__restrict__ vis) {
+    __shared__ uint32_t start[kMaxBins], base[kMaxBins], cnt[kMaxBins];
+    __shared__ uint8_t fits[kMaxBins];
+    __shared__ uint32_t s_wave[kSetupThreads / 64];
+    const uint32_t tid = threadIdx.x;
+    const int nbins = fp.nbx * fp.nby;
+    BinState &st = state[fp.frame & 1u];
+    // every workgroup derives the same bin layout from the totals
+    const uint32_t my_total = int(tid) < nbins ? st.total[tid] : 0u;
+    uint32_t n_entries;
+    const uint32_t my_start = block_exclusive_scan<kSetupThreads / 64>(my_total, s_wave, n_entries);
+    if (int(tid) < nbins) {
+        const bool ok = my_start <= entries_cap && my_total <= entries_cap - my_start;
+        start[tid] = my_start;
+        fits[tid] = ok ? 1 : 0;
+        cnt[tid] = 0;
+        const uint32_t c = dircount[size_t(blockIdx.x) * nbins + tid];
+        base[tid] = (c && ok) ? atomicAdd(&st.cursor[tid], c) : 0u;
+        if (blockIdx.x == 0) {
+            st.start[tid] = my_start;
+            if (!ok && my_total) st.overflow = 1u;
+            if (tid == 0) st.n_entries = n_entries;
         }
-        s_base = base; s_direct = direct;
     }
     __syncthreads();
-    const uint32_t base = s_base;
-    const bool direct = s_direct != 0;
-    for (int q = int(tid); q < nt; q += 256) {
-        dir[size_t(q) * fp.n_groups + blockIdx.x] = direct ? make_uint2(0u, 0u) : make_uint2(base + start[q], count[q]);
-        count[q] = 0;  // becomes the write cursor of the id pass
-    }
-    __syncthreads();
-
-    // id pass: this lane's own records (its stores are visible to itself), grouped by tile
-    k = 0;
-    for (uint32_t t = t_begin + tid; t < t_end; t += 256, k++) {
-#pragma unroll
-        for (int sub = 0; sub < 2; sub++) {
-            if (!((mask[sub] >> k) & 1ull)) continue;
-            const uint32_t id = 2u * t + uint32_t(sub);
-            const BinRec &r = records[id];
-            const int i0 = r.i0, i1 = r.i1, j0 = r.j0, j1 = r.j1;
-            if (direct) {  // index pool exhausted: resolve through the global key buffer
-                Edges e;
-                edges_from_screen(r, e);
-                for (int j = j0; j <= j1; j++) {
-                    const size_t row = size_t(fp.rows - 1 - j) * fp.cols;
-                    for (int i = i0; i <= i1; i++) {
-                        float f[3], zw;
-                        if (cover(e, i, j, f, zw)) vis_min(vis, row + i, make_key(zw, id));
-                    }
-                }
-                continue;
+    const uint32_t n = surv_count[blockIdx.x];
+    const uint32_t *my_surv = surv + size_t(blockIdx.x) * 2 * fp.chunk;
+    for (uint32_t s = tid; s < n; s += kSetupThreads) {
+        const uint32_t id = my_surv[s];
+        const BinRec &r = records[id];
+        const int i0 = r.i0, i1 = r.i1, j0 = r.j0, j1 = r.j1;
+        const int r0 = fp.rows - 1 - j1 - fp.ya, r1 = fp.rows - 1 - j0 - fp.ya;  // rows relative to the strip
+        const int tx0 = i0 >> 6, tx1 = i1 >> 6, ty0 = r0 >> 5, ty1 = r1 >> 5;
+        int bx0, bx1, by0, by1;
+        bin_range(fp, i0, i1, j0, j1, bx0, bx1, by0, by1);
+        bool direct = false;
+        for (int by = by0; by <= by1; by++)
+            for (int bx = bx0; bx <= bx1; bx++) {
+                const int b = by * fp.nbx + bx;
+                if (!fits[b]) { direct = true; continue; }
+                // tiles of this bin inside the record's tile range -> 4x4 bit mask
+                const int ax0 = max(tx0 - 4 * bx, 0), ax1 = min(tx1 - 4 * bx, 3);
+                const int ay0 = max(ty0 - 4 * by, 0), ay1 = min(ty1 - 4 * by, 3);
+                const uint32_t rowbits = ((1u << (ax1 + 1)) - 1u) & ~((1u << ax0) - 1u);
+                uint32_t m = 0;
+                for (int ay = ay0; ay <= ay1; ay++) m |= rowbits << (4 * ay);
+                entries[size_t(start[b]) + base[b] + atomicAdd(&cnt[b], 1u)] = (unsigned long long)id | ((unsigned long long)m << 32);
             }
-            const int tx0 = i0 >> 6, tx1 = i1 >> 6;
-            const int ty0 = (fp.rows - 1 - j1 - fp.ya) >> 5, ty1 = (fp.rows - 1 - j0 - fp.ya) >> 5;
-            for (int ty = ty0; ty <= ty1; ty++)
-                for (int tx = tx0; tx <= tx1; tx++) {
-                    const int tile = ty * fp.ntx + tx;
-                    ipool[size_t(base) + start[tile] + atomicAdd(&count[tile], 1u)] = id;
+        if (direct) {  // a bin it touches has no room: resolve through the global key buffer
+            Edges e;
+            edges_from_screen(r, e);
+            for (int j = j0; j <= j1; j++) {
+                const size_t row = size_t(fp.rows - 1 - j) * fp.cols;
+                for (int i = i0; i <= i1; i++) {
+                    float f[3], zw;
+                    if (cover(e, i, j, f, zw)) vis_min(vis, row + i, make_key(zw, id));
                 }
+            }
         }
     }
 }
 
 // Colour and depth of cell (i, j) from the winner's setup record; unclipped records take their
-// varyings straight from the mesh, clipped ones are rebuilt by shade_cell.
+// varyings from the triangle's attribute row, clipped ones are rebuilt by shade_cell.
 __device__ __forceinline__ void shade_from_record(const FrameParams &fp, const float *__restrict__ vbo,
-                                                  const uint32_t *__restrict__ idx, const BinRec &rec, int i, int j,
-                                                  uint8_t (&px)[4], float &zw) {
+                                                  const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
+                                                  const BinRec &rec, int i, int j, uint8_t (&px)[4], float &zw) {
     if (rec.clipped) { shade_cell(fp, vbo, idx, rec.id, i, j, px, zw); return; }
-    const uint32_t t = rec.id >> 1;
-    const float *a0 = vbo + size_t(idx[3 * size_t(t)]) * 9, *a1 = vbo + size_t(idx[3 * size_t(t) + 1]) * 9,
-                *a2 = vbo + size_t(idx[3 * size_t(t) + 2]) * 9;
+    const float *a = triattr + size_t(rec.id >> 1) * 27;
     Edges e;
     edges_from_screen(rec, e);
     float f[3];
@@ -650,98 +700,100 @@ __device__ __forceinline__ void shade_from_record(const FrameParams &fp, const f
     const float b0 = f[0] * rS, b1 = f[1] * rS, b2 = f[2] * rS;
     float v[9];
 #pragma unroll
-    for (int q = 0; q < 9; q++) v[q] = (b0 * a0[q] + b1 * a1[q]) + b2 * a2[q];
+    for (int q = 0; q < 9; q++) v[q] = (b0 * a[q] + b1 * a[9 + q]) + b2 * a[18 + q];
     shade(fp, v, px);
 }
 
 __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__restrict__ vbo,
-                                              const uint32_t *__restrict__ idx, const BinRec *__restrict__ records,
-                                              const uint32_t *__restrict__ ipool, const uint2 *__restrict__ dir,
-                                              const uint32_t *__restrict__ state, uint64_t *__restrict__ vis,
+                                              const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
+                                              const BinRec *__restrict__ records,
+                                              const unsigned long long *__restrict__ entries, uint32_t entries_cap,
+                                              const BinState *__restrict__ state, uint64_t *__restrict__ vis,
                                               uint8_t *__restrict__ rgba, float *__restrict__ depth,
                                               uint8_t *__restrict__ ascii, uint8_t *__restrict__ ridx,
                                               uint32_t *__restrict__ ids) {
     __shared__ uint64_t keys[kTileCells];
-    __shared__ uint32_t seg_start[kMaxGroups], seg_scan[kMaxGroups + 1];
+    __shared__ uint32_t list[kTileListMax];
     __shared__ uint32_t big[kTileBigMax];
     __shared__ uint16_t covered[kTileCells];
-    __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t n_big, n_cov;
+    __shared__ uint32_t n_list, n_big, n_cov;
     const uint32_t tid = threadIdx.x;
-    const int tile = int(blockIdx.x);
-    const int tx0 = (tile % fp.ntx) * kTileW, tr0 = fp.ya + (tile / fp.ntx) * kTileH;  // first column / output row
+    const int tile_x = int(blockIdx.x) % fp.ntx, tile_y = int(blockIdx.x) / fp.ntx;
+    const int tx0 = tile_x * kTileW, tr0 = fp.ya + tile_y * kTileH;                      // first column / output row
     const int tx1 = min(tx0 + kTileW, fp.cols) - 1, tr1 = min(tr0 + kTileH, fp.yb) - 1;  // last column / row
+    const int bin = (tile_y >> 2) * fp.nbx + (tile_x >> 2);
+    const uint32_t bit = 1u << ((tile_y & 3) * 4 + (tile_x & 3));
+    const BinState &st = state[fp.frame & 1u];
     for (int c = int(tid); c < kTileCells; c += 256) keys[c] = kBackgroundKey;
-    if (tid == 0) { n_big = 0; n_cov = 0; }
-
-    // directory row of this tile -> segment starts and an exclusive scan of the segment lengths
-    const int ng = int(fp.n_groups);
-    const int per = (ng + 255) / 256;
-    const int kb = min(int(tid) * per, ng), ke = min(kb + per, ng);
-    uint32_t sum = 0;
-    for (int k = kb; k < ke; k++) {
-        const uint2 d = dir[size_t(tile) * fp.n_groups + k];
-        seg_start[k] = d.x;
-        seg_scan[k] = sum;
-        sum += d.y;
-    }
-    uint32_t n_rec;
-    const uint32_t off = block_exclusive_scan(sum, s_wave, n_rec);
-    for (int k = kb; k < ke; k++) seg_scan[k] += off;
-    if (tid == 0) seg_scan[ng] = n_rec;
+    if (tid == 0) { n_list = 0; n_big = 0; n_cov = 0; }
+    const uint32_t e_begin = st.start[bin];
+    const uint32_t e_total = st.total[bin];
+    const bool stored = e_begin <= entries_cap && e_total <= entries_cap - e_begin;  // same test as k_fill
+    const uint32_t e_end = stored ? e_begin + e_total : e_begin;
     __syncthreads();
 
-    // records with a small cell range inside the tile: one lane each; the others go to the sweep list
-    for (uint32_t r = tid; r < n_rec; r += 256) {
-        int lo = 0, hi = ng;  // seg_scan[lo] <= r < seg_scan[hi]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (seg_scan[mid] <= r) lo = mid; else hi = mid;
+    // filter the bin's entries by this tile's mask bit into the LDS list; whenever the list could
+    // overflow on the next step (or at the end) rasterise what it holds
+    for (uint32_t eb = e_begin; eb < e_end || eb == e_begin; eb += 256) {
+        const uint32_t e = eb + tid;
+        if (e < e_end) {
+            const unsigned long long ent = entries[e];
+            if (uint32_t(ent >> 32) & bit) list[atomicAdd(&n_list, 1u)] = uint32_t(ent);
         }
-        const uint32_t id = ipool[size_t(seg_start[lo]) + (r - seg_scan[lo])];
-        const BinRec rec = records[id];
-        const int i0 = max(int(rec.i0), tx0), i1 = min(int(rec.i1), tx1);
-        const int r0 = max(fp.rows - 1 - int(rec.j1), tr0), r1 = min(fp.rows - 1 - int(rec.j0), tr1);
-        if ((i1 - i0 + 1) * (r1 - r0 + 1) > kTileSmallCells) {
-            const uint32_t slot = atomicAdd(&n_big, 1u);
-            if (slot < uint32_t(kTileBigMax)) { big[slot] = id; continue; }
-            // list full: this lane scans the range itself (slow but correct)
-        }
-        Edges e;
-        edges_from_screen(rec, e);
-        for (int rr = r0; rr <= r1; rr++) {
-            const int j = fp.rows - 1 - rr;
-            for (int i = i0; i <= i1; i++) {
-                float f[3], zw;
-                if (cover(e, i, j, f, zw))
-                    atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
-                              (unsigned long long)make_key(zw, id));
+        __syncthreads();
+        const uint32_t nl = n_list;
+        const bool last = eb + 256 >= e_end;
+        if (nl + 256 > uint32_t(kTileListMax) || last) {
+            // records with a small cell range inside the tile: one lane each; others -> sweep list
+            for (uint32_t r = tid; r < nl; r += 256) {
+                const uint32_t id = list[r];
+                const BinRec rec = records[id];
+                const int i0 = max(int(rec.i0), tx0), i1 = min(int(rec.i1), tx1);
+                const int r0 = max(fp.rows - 1 - int(rec.j1), tr0), r1 = min(fp.rows - 1 - int(rec.j0), tr1);
+                if ((i1 - i0 + 1) * (r1 - r0 + 1) > kTileSmallCells) {
+                    const uint32_t slot = atomicAdd(&n_big, 1u);
+                    if (slot < uint32_t(kTileBigMax)) { big[slot] = id; continue; }
+                    // list full: this lane scans the range itself (slow but correct)
+                }
+                Edges ed;
+                edges_from_screen(rec, ed);
+                for (int rr = r0; rr <= r1; rr++) {
+                    const int j = fp.rows - 1 - rr;
+                    for (int i = i0; i <= i1; i++) {
+                        float f[3], zw;
+                        if (cover(ed, i, j, f, zw))
+                            atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
+                                      (unsigned long long)make_key(zw, id));
+                    }
+                }
             }
+            __syncthreads();
+            // sweep list: all lanes cover one record's cell range, 256 cells per step
+            const uint32_t nb = min(n_big, uint32_t(kTileBigMax));
+            for (uint32_t b = 0; b < nb; b++) {
+                const BinRec rec = records[big[b]];
+                const int i0 = max(int(rec.i0), tx0), i1 = min(int(rec.i1), tx1);
+                const int r0 = max(fp.rows - 1 - int(rec.j1), tr0), r1 = min(fp.rows - 1 - int(rec.j0), tr1);
+                const int w = i1 - i0 + 1, n = w * (r1 - r0 + 1);
+                Edges ed;
+                edges_from_screen(rec, ed);
+                for (int k = int(tid); k < n; k += 256) {
+                    const int dr = k / w, i = i0 + (k - dr * w), rr = r0 + dr;
+                    float f[3], zw;
+                    if (cover(ed, i, fp.rows - 1 - rr, f, zw))
+                        atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
+                                  (unsigned long long)make_key(zw, rec.id));
+                }
+            }
+            __syncthreads();
+            if (tid == 0) { n_list = 0; n_big = 0; }
+            __syncthreads();
         }
+        if (last) break;
     }
-    __syncthreads();
 
-    // sweep list: all lanes cover one record's cell range, 256 cells per step
-    const uint32_t nb = min(n_big, uint32_t(kTileBigMax));
-    for (uint32_t b = 0; b < nb; b++) {
-        const BinRec rec = records[big[b]];
-        const int i0 = max(int(rec.i0), tx0), i1 = min(int(rec.i1), tx1);
-        const int r0 = max(fp.rows - 1 - int(rec.j1), tr0), r1 = min(fp.rows - 1 - int(rec.j0), tr1);
-        const int w = i1 - i0 + 1, n = w * (r1 - r0 + 1);
-        Edges e;
-        edges_from_screen(rec, e);
-        for (int k = int(tid); k < n; k += 256) {
-            const int dr = k / w, i = i0 + (k - dr * w), rr = r0 + dr;
-            float f[3], zw;
-            if (cover(e, i, fp.rows - 1 - rr, f, zw))
-                atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
-                          (unsigned long long)make_key(zw, rec.id));
-        }
-    }
-    __syncthreads();
-
-    // ids some k_bin workgroup could not store were resolved through the global key buffer
-    if (state[4 * (fp.frame & 1u) + 1] != 0) {
+    // sub-triangles k_fill could not store were resolved through the global key buffer
+    if (st.overflow != 0) {
         for (int c = int(tid); c < kTileCells; c += 256) {
             const int rr = tr0 + (c >> 6), i = tx0 + (c & 63);
             if (i > tx1 || rr > tr1) continue;
@@ -766,7 +818,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
         const uint32_t id = uint32_t(keys[c]);
         uint8_t px[4];
         float zw;
-        shade_from_record(fp, vbo, idx, records[id], i, fp.rows - 1 - rr, px, zw);
+        shade_from_record(fp, vbo, idx, triattr, records[id], i, fp.rows - 1 - rr, px, zw);
         if (fp.want_ids) ids[size_t(rr) * fp.cols + i] = id;
         keys[c] = (uint64_t(__float_as_uint(zw)) << 32) |
                   (uint32_t(px[0]) | (uint32_t(px[1]) << 8) | (uint32_t(px[2]) << 16) | (uint32_t(px[3]) << 24));
@@ -898,12 +950,15 @@ struct ar_ctx {
     uint32_t pool_cap_option = 0;    // 0: sized from the triangle count
     float *d_tripos = nullptr;       // 9 planes x tripos_stride floats: triangle positions
     size_t tripos_stride = 0;
+    float *d_triattr = nullptr;      // n_tris x 27 floats: the three vertices' varyings
     BinRec *d_records = nullptr;     // 2 x n_tris setup records, indexed by id
-    uint32_t *d_pool = nullptr;      // ids grouped by (k_bin workgroup, tile)
+    uint32_t *d_surv = nullptr;      // per k_setup workgroup: ids of its surviving sub-triangles
+    uint32_t *d_surv_count = nullptr;
+    uint32_t *d_dircount = nullptr;  // per k_setup workgroup: entries per bin
+    size_t group_cap = 0, dircount_cap = 0;
+    unsigned long long *d_entries = nullptr;  // (id, tile mask) entries grouped by bin
     uint32_t pool_cap = 0;
-    uint2 *d_dir = nullptr;
-    size_t dir_elems = 0;
-    uint32_t *d_state = nullptr;     // 2 x 4 words, see k_bin
+    BinState *d_state = nullptr;     // two blocks used by alternate frames
     uint32_t frame = 0;              // tiled frames enqueued so far
     bool last_tiled = false;
     uint8_t *d_q_rgba = nullptr, *d_q_ascii = nullptr;
@@ -1023,32 +1078,43 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
     const unsigned cell_blocks = unsigned((strip_cells + 255) / 256);
     fp.ntx = (cols + kTileW - 1) / kTileW;
     fp.nty = (fp.yb - fp.ya + kTileH - 1) / kTileH;
+    fp.nbx = (fp.ntx + 3) / 4;
+    fp.nby = (fp.nty + 3) / 4;
     const size_t nt = size_t(fp.ntx) * fp.nty;
-    const bool tiled = ctx->path == 0 && nt <= size_t(kMaxTiles) && cols <= 65535 && rows <= 65535 && ctx->d_tripos &&
-                       (fp.n_tris + kMaxGroups - 1) / kMaxGroups <= kMaxChunk;
+    const size_t nbins = size_t(fp.nbx) * fp.nby;
+    const bool tiled = ctx->path == 0 && nt <= size_t(kMaxTiles) && nbins <= size_t(kMaxBins) && cols <= 65535 &&
+                       rows <= 65535 && ctx->d_tripos;
     if (tiled) {
-        // k_bin workgroups: chunks of >= 2048 consecutive triangles, at most kMaxGroups of them
-        uint32_t chunk = (fp.n_tris + kMaxGroups - 1) / kMaxGroups;
-        chunk = (chunk + 255u) / 256u * 256u;
-        if (chunk < 2048u) chunk = 2048u;
+        // k_setup workgroups take chunks of 1024..4096 consecutive triangles (1..4 per lane)
+        uint32_t chunk = (fp.n_tris / 512u + 1023u) / 1024u * 1024u;
+        chunk = chunk < 1024u ? 1024u : (chunk > 4096u ? 4096u : chunk);
         fp.chunk = chunk;
         fp.n_groups = (fp.n_tris + chunk - 1) / chunk;
         fp.frame = ctx->frame;
         const uint32_t want_cap = ctx->pool_cap_option ? ctx->pool_cap_option : 2u * fp.n_tris + 65536u;
-        if (!ctx->d_pool || ctx->pool_cap != want_cap) {
+        if (!ctx->d_entries || ctx->pool_cap != want_cap) {
             AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            (void)hipFree(ctx->d_pool);
-            ctx->d_pool = nullptr; ctx->pool_cap = 0;
-            AR_HIP(ctx, hipMalloc(&ctx->d_pool, size_t(want_cap) * sizeof(uint32_t)));
+            (void)hipFree(ctx->d_entries);
+            ctx->d_entries = nullptr; ctx->pool_cap = 0;
+            AR_HIP(ctx, hipMalloc(&ctx->d_entries, size_t(want_cap) * sizeof(unsigned long long)));
             ctx->pool_cap = want_cap;
         }
-        const size_t want_dir = nt * fp.n_groups;
-        if (!ctx->d_dir || ctx->dir_elems < want_dir) {
+        const size_t want_groups = size_t(fp.n_groups) * 2 * chunk;
+        if (!ctx->d_surv || ctx->group_cap < want_groups) {
             AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            (void)hipFree(ctx->d_dir);
-            ctx->d_dir = nullptr; ctx->dir_elems = 0;
-            AR_HIP(ctx, hipMalloc(&ctx->d_dir, want_dir * sizeof(uint2)));
-            ctx->dir_elems = want_dir;
+            (void)hipFree(ctx->d_surv); (void)hipFree(ctx->d_surv_count);
+            ctx->d_surv = nullptr; ctx->d_surv_count = nullptr; ctx->group_cap = 0;
+            AR_HIP(ctx, hipMalloc(&ctx->d_surv, want_groups * sizeof(uint32_t)));
+            AR_HIP(ctx, hipMalloc(&ctx->d_surv_count, (want_groups / 2048 + 1) * sizeof(uint32_t)));
+            ctx->group_cap = want_groups;
+        }
+        const size_t want_dir = size_t(fp.n_groups) * nbins;
+        if (!ctx->d_dircount || ctx->dircount_cap < want_dir) {
+            AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->d_dircount);
+            ctx->d_dircount = nullptr; ctx->dircount_cap = 0;
+            AR_HIP(ctx, hipMalloc(&ctx->d_dircount, want_dir * sizeof(uint32_t)));
+            ctx->dircount_cap = want_dir;
         }
     }
     const bool was_clean = ctx->vis_clean;
@@ -1058,22 +1124,26 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
         // consumes a visibility key, a queue counter or a binning state word puts it back to its
         // idle value, so no per-frame clear is needed.
         AR_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
-        AR_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, 8 * sizeof(uint32_t), ctx->stream));
+        AR_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, 2 * sizeof(BinState), ctx->stream));
         Stamper s(ctx, K_CLEAR);
         k_clear<<<2048, 256, 0, ctx->stream>>>(ctx->d_vis, 0, size_t(cols) * rows);
     }
     if (tiled) {
         {
-            Stamper s(ctx, K_BIN);
-            k_bin<<<fp.n_groups, 256, 2 * nt * sizeof(uint32_t), ctx->stream>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_records,
-                                                                               ctx->d_pool, ctx->pool_cap, ctx->d_dir, ctx->d_state,
-                                                                               ctx->d_vis);
+            Stamper s(ctx, K_SETUP);
+            k_setup<<<fp.n_groups, kSetupThreads, 0, ctx->stream>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_records, ctx->d_surv,
+                                                                   ctx->d_surv_count, ctx->d_dircount, ctx->d_state);
+        }
+        {
+            Stamper s(ctx, K_FILL);
+            k_fill<<<fp.n_groups, kSetupThreads, 0, ctx->stream>>>(fp, ctx->d_records, ctx->d_surv, ctx->d_surv_count, ctx->d_dircount,
+                                                                  ctx->d_state, ctx->d_entries, ctx->pool_cap, ctx->d_vis);
         }
         {
             Stamper s(ctx, K_TILE);
-            k_tile<<<unsigned(nt), 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_records, ctx->d_pool, ctx->d_dir,
-                                                         ctx->d_state, ctx->d_vis, ctx->d_rgba, ctx->d_depth, ctx->d_ascii,
-                                                         ctx->d_ridx, ctx->d_ids);
+            k_tile<<<unsigned(nt), 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_records, ctx->d_entries,
+                                                         ctx->pool_cap, ctx->d_state, ctx->d_vis, ctx->d_rgba, ctx->d_depth,
+                                                         ctx->d_ascii, ctx->d_ridx, ctx->d_ids);
         }
         ctx->frame++;
     } else {
@@ -1125,8 +1195,8 @@ ar_ctx *ar_create(int device_id) {
               hipMalloc(&ctx->d_large, size_t(kLargeCapacity) * sizeof(TriRec)) == hipSuccess &&
               hipMalloc(&ctx->d_counters, 4 * sizeof(uint32_t)) == hipSuccess &&
               hipMemset(ctx->d_counters, 0, 4 * sizeof(uint32_t)) == hipSuccess &&
-              hipMalloc(&ctx->d_state, 8 * sizeof(uint32_t)) == hipSuccess &&
-              hipMemset(ctx->d_state, 0, 8 * sizeof(uint32_t)) == hipSuccess;
+              hipMalloc(&ctx->d_state, 2 * sizeof(BinState)) == hipSuccess &&
+              hipMemset(ctx->d_state, 0, 2 * sizeof(BinState)) == hipSuccess;
     if (!ok) {
         fail(nullptr, AR_E_HIP, "context setup failed: %s", hipGetErrorString(hipGetLastError()));
         ar_destroy(ctx);
@@ -1153,8 +1223,8 @@ void ar_destroy(ar_ctx *ctx) {
     (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx);
     (void)hipFree(ctx->d_medium); (void)hipFree(ctx->d_large); (void)hipFree(ctx->d_counters);
     (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii);
-    (void)hipFree(ctx->d_pool); (void)hipFree(ctx->d_dir); (void)hipFree(ctx->d_state);
-    (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_records);
+    (void)hipFree(ctx->d_entries); (void)hipFree(ctx->d_state); (void)hipFree(ctx->d_surv); (void)hipFree(ctx->d_surv_count);
+    (void)hipFree(ctx->d_dircount); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr); (void)hipFree(ctx->d_records);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1167,8 +1237,9 @@ int ar_set_mesh(ar_ctx *ctx, const float *vbo9, uint32_t n_verts, const uint32_t
     if (n_tris && (!vbo9 || !idx || !n_verts)) return fail(ctx, AR_E_ARG, "ar_set_mesh: null buffer with %u triangles", n_tris);
     AR_HIP(ctx, hipSetDevice(ctx->device));
     AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_records);
-    ctx->d_vbo = nullptr; ctx->d_idx = nullptr; ctx->d_tripos = nullptr; ctx->d_records = nullptr;
+    (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr);
+    (void)hipFree(ctx->d_records);
+    ctx->d_vbo = nullptr; ctx->d_idx = nullptr; ctx->d_tripos = nullptr; ctx->d_triattr = nullptr; ctx->d_records = nullptr;
     ctx->n_verts = 0; ctx->n_tris = 0;
     if (!n_tris) return 0;
     AR_HIP(ctx, hipMalloc(&ctx->d_vbo, size_t(n_verts) * 9 * sizeof(float)));
@@ -1178,8 +1249,10 @@ int ar_set_mesh(ar_ctx *ctx, const float *vbo9, uint32_t n_verts, const uint32_t
     // derived, position-only stream for the binning pass and the per-id record store of the tiled path
     ctx->tripos_stride = (size_t(n_tris) + 63) / 64 * 64;
     AR_HIP(ctx, hipMalloc(&ctx->d_tripos, 9 * ctx->tripos_stride * sizeof(float)));
+    AR_HIP(ctx, hipMalloc(&ctx->d_triattr, size_t(n_tris) * 27 * sizeof(float)));
     AR_HIP(ctx, hipMalloc(&ctx->d_records, 2 * size_t(n_tris) * sizeof(BinRec)));
-    k_tripos<<<(n_tris + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_vbo, ctx->d_idx, n_verts, n_tris, ctx->tripos_stride, ctx->d_tripos);
+    k_tristream<<<(n_tris + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_vbo, ctx->d_idx, n_verts, n_tris, ctx->tripos_stride, ctx->d_tripos,
+                                                              ctx->d_triattr);
     AR_HIP(ctx, hipGetLastError());
     AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_verts = n_verts; ctx->n_tris = n_tris;
@@ -1343,16 +1416,15 @@ int ar_frame_counters(ar_ctx *ctx, uint32_t out[8]) {
     if (!ctx || !out) return AR_E_ARG;
     AR_HIP(ctx, hipSetDevice(ctx->device));
     AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    uint32_t c[4] = {0, 0, 0, 0}, st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t c[4] = {0, 0, 0, 0}, last[2] = {0, 0};  // last: {overflow, n_entries} of the last tiled frame
     AR_HIP(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
-    AR_HIP(ctx, hipMemcpy(st, ctx->d_state, sizeof st, hipMemcpyDeviceToHost));
-    const uint32_t *last = st + 4 * ((ctx->frame + 1u) & 1u);  // block of the last tiled frame
+    AR_HIP(ctx, hipMemcpy(last, &ctx->d_state[(ctx->frame + 1u) & 1u].overflow, sizeof last, hipMemcpyDeviceToHost));
     for (int k = 0; k < 8; k++) out[k] = 0;
     out[0] = ctx->n_tris;
     out[1] = ctx->last_tiled ? 0 : c[2];
     out[2] = ctx->last_tiled ? 0 : c[3];
-    out[3] = ctx->last_tiled ? last[0] : 0;
-    out[4] = ctx->last_tiled ? last[1] : 0;
+    out[3] = ctx->last_tiled ? last[1] : 0;
+    out[4] = ctx->last_tiled ? last[0] : 0;
     out[5] = ctx->last_tiled ? 1u : 0u;
     return 0;
 }

@@ -97,21 +97,21 @@ int ar_quantize(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *a
 /* Per-kernel timing with HIP events on the context's stream.  While on, every launch is bracketed by
  * events; ar_kernel_stats drains them (blocking) and reports, per kernel slot, the number of launches
  * and the summed duration in milliseconds since the last call.  names receives static strings. */
-#define AR_N_KERNELS 8
+#define AR_N_KERNELS 9
 int ar_set_profiling(ar_ctx *ctx, int on);
 int ar_kernel_stats(ar_ctx *ctx, const char *names[AR_N_KERNELS], uint32_t launches[AR_N_KERNELS], float total_ms[AR_N_KERNELS]);
 
 /* Counters of the last rendered frame: [0] triangles submitted; direct path: [1] records queued for
- * the medium-triangle pass, [2] for the large-triangle pass; tiled path: [3] (triangle, tile) records
+ * the medium-triangle pass, [2] for the large-triangle pass; tiled path: [3] (sub-triangle, bin) entries
  * binned, [4] 1 when the record pool overflowed (the frame is still correct, but slower), [5] 1 when
  * the frame took the tiled path; [6..7] reserved. */
 int ar_frame_counters(ar_ctx *ctx, uint32_t out[8]);
 
 /* Tuning / test switches (no counterpart in the reference).
  *   AR_OPT_PATH          0 (default): tile-binned path whenever the grid has at most 8000 tiles of
- *                        64x32 cells, else the direct path; 1: always the direct path (every
+ *                        64x32 cells (512 bins of 4x4 tiles), else the direct path; 1: always the direct path (every
  *                        fragment resolved with a 64-bit atomic min in HBM).
- *   AR_OPT_POOL_RECORDS  capacity of the tiled path's (triangle, tile) index pool in entries;
+ *   AR_OPT_POOL_RECORDS  capacity of the tiled path's (sub-triangle, bin) entry pool in entries;
  *                        0 (default) sizes it as 2 x triangles + 65536. */
 #define AR_OPT_PATH 1
 #define AR_OPT_POOL_RECORDS 2

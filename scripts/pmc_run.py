@@ -1,0 +1,14 @@
+"""Renders a few C3 frames (for rocprofv3 --pmc passes; keep it short)."""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ar = importlib.import_module("ascii-renderer_amd")
+tris = int(os.environ.get("AR_TRIS", "1000000")); cols = int(os.environ.get("AR_COLS", "1920")); rows = int(os.environ.get("AR_ROWS", "1080"))
+sc = ar.scenes.random_scene(tris, cols, rows)
+R = ar.Renderer(0)
+if os.environ.get("AR_PATH") == "direct":
+    R.set_option("path", 1)
+ar.scenes.upload(R, sc)
+for _ in range(int(os.environ.get("AR_FRAMES", "5"))):
+    R.render_async(cols, rows)
+R.sync()
+print("done", R.frame_counters())
