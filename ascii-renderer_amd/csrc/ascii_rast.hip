@@ -35,10 +35,10 @@ constexpr int kMediumMaxCells = 4096;   // above this a record goes to the per-c
 constexpr uint32_t kMediumCapacity = 1u << 18;
 constexpr uint32_t kLargeCapacity = 1u << 14;
 
-enum KernelSlot { K_CLEAR = 0, K_RASTER, K_MEDIUM, K_LARGE, K_SHADE, K_ASCII, K_SETUP, K_FILL, K_TILE };
+enum KernelSlot { K_CLEAR = 0, K_RASTER, K_MEDIUM, K_LARGE, K_SHADE, K_ASCII, K_SETUP, K_BINSCAN, K_FILL, K_TILE };
 const char *const kKernelNames[AR_N_KERNELS] = {"k_clear",  "k_raster", "k_raster_medium", "k_raster_large",
-                                                "k_shade", "k_ascii",  "k_setup",         "k_fill",
-                                                "k_tile"};
+                                                "k_shade", "k_ascii",  "k_setup",         "k_binscan",
+                                                "k_fill",  "k_tile"};
 
 // Everything a frame's kernels need besides the big buffers; passed by value as a kernel argument.
 struct FrameParams {
@@ -54,7 +54,7 @@ struct FrameParams {
     int ramp_len, mode_on, mode_radius, mode_thresh;
     int want_ids;    // also store the winning (2*triangle + sub) per cell
     int ntx, nty;    // tile grid over columns [0, cols) x output rows [ya, yb)
-    int nbx, nby;    // bin grid (4x4 tiles per bin)
+    int nbx, nby;    // bin grid (2x2 tiles per bin)
     uint32_t chunk, n_groups;  // triangles per k_setup workgroup, number of those workgroups
     uint32_t frame;  // frame counter (selects the binning state block)
     uint8_t ramp[AR_MAX_RAMP];
@@ -438,21 +438,25 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__re
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tiled path: sub-triangles are binned to screen bins of 4x4 tiles, each 64x32-cell tile is
+// Tiled path: sub-triangles are binned to screen bins of 2x2 tiles, each 64x32-cell tile is
 // resolved in LDS.
 //
 //   k_tristream (at mesh upload) gathers, per triangle, the three positions into nine planes of
-//             n_tris floats (36 contiguous, coalesced bytes per triangle for the per-frame pass) and
-//             the three vertices' 9 varyings into one 108-byte row (one gather per shaded cell
-//             instead of index -> vertex chasing).
+//             n_tris floats (36 contiguous, coalesced bytes per triangle for the per-frame pass),
+//             the three vertices' varyings into one 108-byte row (one gather per shaded cell
+//             instead of index -> vertex chasing) and a flag telling whether the triangle is flat
+//             (identical normal and colour at its three vertices).
 //   k_setup   one pass over the positions, one lane per triangle slot: transform, near clip, cull,
 //             cell range.  Every sub-triangle that can produce fragments gets its 64-byte setup
 //             record at records[id] (id = 2*triangle + sub), its id appended to the workgroup's
 //             survivor list, and is counted into the workgroup's LDS histogram over bins, which is
-//             then published (one row of the count table, one global atomic per non-empty bin).
+//             then published as one row of the count table.
+//   k_binscan column-wise exclusive prefix of the count table over the k_setup workgroups (in place)
+//             and the bin totals: every (workgroup, bin) pair gets a fixed slice of the bin's entry
+//             array without a single global atomic.
 //   k_fill    exclusive scan of the bin totals -> start of each bin's entry array; every workgroup
-//             reserves its share of each bin with one returning atomic and writes one entry
-//             (id, 16-bit mask of the bin's tiles the cell range touches) per (survivor, bin).
+//             writes one entry (id, mask of the bin's tiles the cell range touches) per (survivor,
+//             bin) into its slices.
 //   k_tile    one workgroup per tile: filters its bin's entries by mask bit into an LDS work list,
 //             rasterises those records into a 2048-entry LDS key tile with LDS atomic min (small
 //             cell ranges: one lane per record; large ones: all lanes sweep the range), then shades
@@ -463,26 +467,30 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__re
 // that buffer in.
 // ------------------------------------------------------------------------------------------------
 constexpr int kTileW = 64, kTileH = 32, kTileCells = kTileW * kTileH;
+constexpr int kBinShift = 1;          // a bin is 2x2 tiles = 128x64 cells
+constexpr int kBinSide = 1 << kBinShift;
 constexpr int kMaxTiles = 8000;       // tiles per frame the tiled path accepts
-constexpr int kMaxBins = 512;         // bins of 4x4 tiles (8000 / 16 rounded up)
+constexpr int kMaxBins = 2048;        // >= kMaxTiles / 4 for any tile-grid shape the path accepts
 constexpr int kSetupThreads = 1024;   // k_setup / k_fill workgroup size
+constexpr int kSetupPerLane = 4;      // triangles per lane of k_setup (chunk <= 4096)
 constexpr int kTileBigMax = 512;      // per-tile list of records swept cooperatively
 constexpr int kTileSmallCells = 64;   // cell-range area (inside the tile) one lane scans itself
 constexpr int kTileListMax = 2048;    // ids staged in LDS between the filter and the raster step
+constexpr uint32_t kFlagClipped = 1u; // record produced by the near-plane clip (vertices differ from the mesh's)
+constexpr uint32_t kFlagFlat = 2u;    // the triangle's three vertices carry identical normal and colour
 
 struct __align__(16) BinRec {
     float X[3], Y[3], W[3], Z[3];
     uint32_t id;              // 2*triangle + sub-triangle
     uint16_t i0, i1, j0, j1;  // inclusive cell range, GL window rows (y up)
-    uint32_t clipped;         // 1: produced by the near-plane clip (vertices differ from the mesh's)
+    uint32_t flags;           // kFlagClipped | kFlagFlat
 };
 static_assert(sizeof(BinRec) == 64, "bin records are four 16-byte loads");
 
-// Per-frame binning state, double-buffered by frame parity so that the kernels of frame f can zero
-// the block frame f+1 will use: total[b] entries of bin b, cursor[b] entries already reserved.
+// Per-frame binning state, double-buffered by frame parity so that the kernels of frame f can reset
+// the block frame f+1 will use: total[b] entries of bin b.
 struct BinState {
     uint32_t total[kMaxBins];
-    uint32_t cursor[kMaxBins];
     uint32_t start[kMaxBins];   // exclusive scan of total (written by k_fill's first workgroup)
     uint32_t overflow;          // some bin did not fit the entry pool
     uint32_t n_entries;         // sum of total
@@ -514,24 +522,42 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
     return off + incl - v;
 }
 
-// Per triangle: positions -> planes pos[k*stride + t] (k = 3*vertex + axis) and the 27 varyings of
-// its vertices -> attr[t*27 ..].  A triangle that names a vertex outside the buffer gets NaN
-// positions, which every later stage rejects.
+// Per triangle: positions -> planes pos[k*stride + t] (k = 3*vertex + axis); varyings -> attr[t*27 ..]
+// laid out (normal, colour) x 3 vertices, then position x 3 vertices (positions are only read when
+// point lights are on); flat[t] = 1 when the three normals and the three colours are identical.
+// A triangle that names a vertex outside the buffer gets NaN positions, which every later stage rejects.
 __global__ __launch_bounds__(256) void k_tristream(const float *__restrict__ vbo, const uint32_t *__restrict__ idx,
                                                    uint32_t n_verts, uint32_t n_tris, size_t stride,
-                                                   float *__restrict__ pos, float *__restrict__ attr) {
+                                                   float *__restrict__ pos, float *__restrict__ attr,
+                                                   uint8_t *__restrict__ flat) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n_tris) return;
+    float a[3][9];
+    bool all_ok = true;
 #pragma unroll
     for (int v = 0; v < 3; v++) {
         const uint32_t vi = idx[3 * size_t(t) + v];
         const bool ok = vi < n_verts;
+        all_ok = all_ok && ok;
         const float *p = vbo + size_t(ok ? vi : 0u) * 9;
 #pragma unroll
-        for (int ax = 0; ax < 3; ax++) pos[size_t(3 * v + ax) * stride + t] = ok ? p[ax] : __builtin_nanf("");
+        for (int q = 0; q < 9; q++) a[v][q] = ok ? p[q] : 0.0f;
 #pragma unroll
-        for (int q = 0; q < 9; q++) attr[size_t(t) * 27 + 9 * v + q] = ok ? p[q] : 0.0f;
+        for (int ax = 0; ax < 3; ax++) pos[size_t(3 * v + ax) * stride + t] = ok ? p[ax] : __builtin_nanf("");
     }
+    float *row = attr + size_t(t) * 27;
+    bool is_flat = all_ok;
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            row[6 * v + q] = a[v][3 + q];
+            is_flat = is_flat && (__float_as_uint(a[v][3 + q]) == __float_as_uint(a[0][3 + q]));
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) row[18 + 3 * v + q] = a[v][q];
+    }
+    flat[t] = is_flat ? 1 : 0;
 }
 
 __device__ __forceinline__ Vert<0> transform_position(const FrameParams &fp, float x, float y, float z) {
@@ -542,14 +568,11 @@ __device__ __forceinline__ Vert<0> transform_position(const FrameParams &fp, flo
     return o;
 }
 
-// Calls f(screen, i0, i1, j0, j1, sub, clipped) for every sub-triangle of triangle t that can produce
-// fragments in window rows [jlo, jhi]: transformed, near-clipped, front facing, non-empty cell range.
+// Calls f(screen, i0, i1, j0, j1, sub, clipped) for every sub-triangle of the triangle with vertex
+// positions p[0..8] that can produce fragments in window rows [jlo, jhi]: transformed, near-clipped,
+// front facing, non-empty cell range.
 template <typename F>
-__device__ __forceinline__ void for_each_subtri(const FrameParams &fp, const float *__restrict__ tripos, size_t stride,
-                                                uint32_t t, int jlo, int jhi, F &&f) {
-    float p[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) p[k] = tripos[size_t(k) * stride + t];
+__device__ __forceinline__ void for_each_subtri(const FrameParams &fp, const float (&p)[9], int jlo, int jhi, F &&f) {
     const Vert<0> in0 = transform_position(fp, p[0], p[1], p[2]), in1 = transform_position(fp, p[3], p[4], p[5]),
                   in2 = transform_position(fp, p[6], p[7], p[8]);
     Vert<0> s0[3], s1[3];
@@ -565,61 +588,104 @@ __device__ __forceinline__ void for_each_subtri(const FrameParams &fp, const flo
     }
 }
 
-// Range of bins (4x4 tiles = 256x128 cells) a cell range touches.
+// Range of bins a cell range touches.
 __device__ __forceinline__ void bin_range(const FrameParams &fp, int i0, int i1, int j0, int j1, int &bx0, int &bx1,
                                           int &by0, int &by1) {
-    bx0 = i0 >> 8; bx1 = i1 >> 8;
-    by0 = (fp.rows - 1 - j1 - fp.ya) >> 7; by1 = (fp.rows - 1 - j0 - fp.ya) >> 7;
+    bx0 = i0 >> (6 + kBinShift); bx1 = i1 >> (6 + kBinShift);
+    by0 = (fp.rows - 1 - j1 - fp.ya) >> (5 + kBinShift); by1 = (fp.rows - 1 - j0 - fp.ya) >> (5 + kBinShift);
 }
 
+// surv: per workgroup a list of (id, i0 | i1 << 16, j0 | j1 << 16, flags) for its surviving sub-triangles.
 __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const float *__restrict__ tripos, size_t stride,
-                                                         BinRec *__restrict__ records, uint32_t *__restrict__ surv,
-                                                         uint32_t *__restrict__ surv_count, uint32_t *__restrict__ dircount,
-                                                         BinState *__restrict__ state) {
+                                                         const uint8_t *__restrict__ flat, BinRec *__restrict__ records,
+                                                         uint4 *__restrict__ surv, uint32_t *__restrict__ surv_count,
+                                                         uint32_t *__restrict__ dircount, BinState *__restrict__ state) {
     __shared__ uint32_t hist[kMaxBins];
     __shared__ uint32_t n_surv;
     const uint32_t tid = threadIdx.x;
     const int nbins = fp.nbx * fp.nby;
-    for (int k = int(tid); k < nbins; k += kSetupThreads) hist[k] = 0;
-    if (tid == 0) n_surv = 0;
-    BinState &st = state[fp.frame & 1u], &st_next = state[(fp.frame + 1u) & 1u];
-    if (blockIdx.x == 0) {  // idle values for the next frame
-        for (int k = int(tid); k < kMaxBins; k += kSetupThreads) { st_next.total[k] = 0; st_next.cursor[k] = 0; }
-        if (tid == 0) { st_next.overflow = 0; st_next.n_entries = 0; }
-    }
-    __syncthreads();
     const uint32_t t_begin = blockIdx.x * fp.chunk;
     const uint32_t t_end = min(t_begin + fp.chunk, fp.n_tris);
+    // all of this lane's triangles are fetched before the first one is processed
+    float p[kSetupPerLane][9];
+    uint32_t fl[kSetupPerLane];
+#pragma unroll
+    for (int k = 0; k < kSetupPerLane; k++) {
+        const uint32_t t = t_begin + tid + uint32_t(k) * kSetupThreads;
+        const bool live = t < t_end && uint32_t(k) * kSetupThreads < fp.chunk;
+        const uint32_t tt = live ? t : t_begin;
+#pragma unroll
+        for (int q = 0; q < 9; q++) p[k][q] = tripos[size_t(q) * stride + tt];
+        fl[k] = flat[tt] ? kFlagFlat : 0u;
+    }
+    for (int k = int(tid); k < nbins; k += kSetupThreads) hist[k] = 0;
+    if (tid == 0) n_surv = 0;
+    BinState &st_next = state[(fp.frame + 1u) & 1u];
+    if (blockIdx.x == 0 && tid == 0) { st_next.overflow = 0; st_next.n_entries = 0; }  // idle values for the next frame
+    __syncthreads();
     const int jlo = fp.rows - fp.yb, jhi = fp.rows - 1 - fp.ya;
-    uint32_t *my_surv = surv + size_t(blockIdx.x) * 2 * fp.chunk;
+    uint4 *my_surv = surv + size_t(blockIdx.x) * 2 * fp.chunk;
 
-    for (uint32_t t = t_begin + tid; t < t_end; t += kSetupThreads)
-        for_each_subtri(fp, tripos, stride, t, jlo, jhi,
-                        [&](const Screen &sc, int i0, int i1, int j0, int j1, int sub, bool clipped) {
+#pragma unroll
+    for (int k = 0; k < kSetupPerLane; k++) {
+        const uint32_t t = t_begin + tid + uint32_t(k) * kSetupThreads;
+        if (!(t < t_end && uint32_t(k) * kSetupThreads < fp.chunk)) continue;
+        for_each_subtri(fp, p[k], jlo, jhi, [&](const Screen &sc, int i0, int i1, int j0, int j1, int sub, bool clipped) {
             BinRec r;
 #pragma unroll
             for (int q = 0; q < 3; q++) { r.X[q] = sc.X[q]; r.Y[q] = sc.Y[q]; r.W[q] = sc.W[q]; r.Z[q] = sc.Z[q]; }
             r.id = 2u * t + uint32_t(sub);
             r.i0 = uint16_t(i0); r.i1 = uint16_t(i1); r.j0 = uint16_t(j0); r.j1 = uint16_t(j1);
-            r.clipped = clipped ? 1u : 0u;
+            r.flags = (clipped ? kFlagClipped : 0u) | fl[k];
             records[r.id] = r;
-            my_surv[atomicAdd(&n_surv, 1u)] = r.id;
+            my_surv[atomicAdd(&n_surv, 1u)] = make_uint4(r.id, uint32_t(i0) | (uint32_t(i1) << 16),
+                                                         uint32_t(j0) | (uint32_t(j1) << 16), r.flags);
             int bx0, bx1, by0, by1;
             bin_range(fp, i0, i1, j0, j1, bx0, bx1, by0, by1);
             for (int by = by0; by <= by1; by++)
                 for (int bx = bx0; bx <= bx1; bx++) atomicAdd(&hist[by * fp.nbx + bx], 1u);
         });
-    __syncthreads();
-    for (int k = int(tid); k < nbins; k += kSetupThreads) {
-        const uint32_t c = hist[k];
-        dircount[size_t(blockIdx.x) * nbins + k] = c;
-        if (c) atomicAdd(&st.total[k], c);
     }
+    __syncthreads();
+    for (int k = int(tid); k < nbins; k += kSetupThreads) dircount[size_t(blockIdx.x) * nbins + k] = hist[k];
     if (tid == 0) surv_count[blockIdx.x] = n_surv;
 }
 
+// Column-wise exclusive prefix over the k_setup workgroups of the count table, in place: afterwards
+// table[g][b] = entries of bin b that belong to workgroups before g, and total[b] = all of them.
+// One workgroup per 64 bins; its 16 wavefronts split the rows, so no global atomics are needed and
+// the layout of every bin's entry array is the same on every run.
+__global__ __launch_bounds__(1024) void k_binscan(FrameParams fp, uint32_t *__restrict__ table, BinState *__restrict__ state) {
+    __shared__ uint32_t part[16][64];
+    const int nbins = fp.nbx * fp.nby;
+    const int lane = int(threadIdx.x & 63u), rg = int(threadIdx.x >> 6);
+    const int b = int(blockIdx.x) * 64 + lane;
+    const uint32_t rows_per = (fp.n_groups + 15u) / 16u;
+    const uint32_t g0 = min(uint32_t(rg) * rows_per, fp.n_groups), g1 = min(g0 + rows_per, fp.n_groups);
+    uint32_t sum = 0;
+    if (b < nbins)
+        for (uint32_t g = g0; g < g1; g++) sum += table[size_t(g) * nbins + b];
+    part[rg][lane] = sum;
+    __syncthreads();
+    uint32_t run = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t x = part[k][lane];
+        if (k < rg) run += x;
+        tot += x;
+    }
+    if (b < nbins) {
+        for (uint32_t g = g0; g < g1; g++) {
+            const uint32_t v = table[size_t(g) * nbins + b];
+            table[size_t(g) * nbins + b] = run;
+            run += v;
+        }
+        if (rg == 0) state[fp.frame & 1u].total[b] = tot;
+    }
+}
+
 __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const BinRec *__restrict__ records,
-                                                        const uint32_t *__restrict__ surv,
+                                                        const uint4 *__restrict__ surv,
                                                         const uint32_t *__restrict__ surv_count,
                                                         const uint32_t *__restrict__ dircount, BinState *__restrict__ state,
                                                         unsigned long long *__restrict__ entries, uint32_t entries_cap,
@@ -630,30 +696,29 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Bi
     const uint32_t tid = threadIdx.x;
     const int nbins = fp.nbx * fp.nby;
     BinState &st = state[fp.frame & 1u];
-    // every workgroup derives the same bin layout from the totals
-    const uint32_t my_total = int(tid) < nbins ? st.total[tid] : 0u;
+    // each lane owns bins 2*tid and 2*tid + 1: this workgroup's offset inside them comes from the
+    // scanned count table, the start of each bin's array from an exclusive scan of the totals
+    const int b0 = 2 * int(tid), b1 = b0 + 1;
+    const uint32_t base0 = b0 < nbins ? dircount[size_t(blockIdx.x) * nbins + b0] : 0u;
+    const uint32_t base1 = b1 < nbins ? dircount[size_t(blockIdx.x) * nbins + b1] : 0u;
+    const uint32_t t0 = b0 < nbins ? st.total[b0] : 0u, t1 = b1 < nbins ? st.total[b1] : 0u;
+    const uint32_t n = surv_count[blockIdx.x];
     uint32_t n_entries;
-    const uint32_t my_start = block_exclusive_scan<kSetupThreads / 64>(my_total, s_wave, n_entries);
-    if (int(tid) < nbins) {
-        const bool ok = my_start <= entries_cap && my_total <= entries_cap - my_start;
-        start[tid] = my_start;
-        fits[tid] = ok ? 1 : 0;
-        cnt[tid] = 0;
-        const uint32_t c = dircount[size_t(blockIdx.x) * nbins + tid];
-        base[tid] = (c && ok) ? atomicAdd(&st.cursor[tid], c) : 0u;
-        if (blockIdx.x == 0) {
-            st.start[tid] = my_start;
-            if (!ok && my_total) st.overflow = 1u;
-            if (tid == 0) st.n_entries = n_entries;
-        }
+    const uint32_t s0 = block_exclusive_scan<kSetupThreads / 64>(t0 + t1, s_wave, n_entries), s1 = s0 + t0;
+    const bool ok0 = s0 <= entries_cap && t0 <= entries_cap - s0, ok1 = s1 <= entries_cap && t1 <= entries_cap - s1;
+    if (b0 < nbins) { start[b0] = s0; base[b0] = base0; cnt[b0] = 0; fits[b0] = ok0 ? 1 : 0; }
+    if (b1 < nbins) { start[b1] = s1; base[b1] = base1; cnt[b1] = 0; fits[b1] = ok1 ? 1 : 0; }
+    if (blockIdx.x == 0) {
+        if (b0 < nbins) { st.start[b0] = s0; if (!ok0 && t0) st.overflow = 1u; }
+        if (b1 < nbins) { st.start[b1] = s1; if (!ok1 && t1) st.overflow = 1u; }
+        if (tid == 0) st.n_entries = n_entries;
     }
     __syncthreads();
-    const uint32_t n = surv_count[blockIdx.x];
-    const uint32_t *my_surv = surv + size_t(blockIdx.x) * 2 * fp.chunk;
+    const uint4 *my_surv = surv + size_t(blockIdx.x) * 2 * fp.chunk;
     for (uint32_t s = tid; s < n; s += kSetupThreads) {
-        const uint32_t id = my_surv[s];
-        const BinRec &r = records[id];
-        const int i0 = r.i0, i1 = r.i1, j0 = r.j0, j1 = r.j1;
+        const uint4 sv = my_surv[s];
+        const uint32_t id = sv.x;
+        const int i0 = int(sv.y & 0xFFFFu), i1 = int(sv.y >> 16), j0 = int(sv.z & 0xFFFFu), j1 = int(sv.z >> 16);
         const int r0 = fp.rows - 1 - j1 - fp.ya, r1 = fp.rows - 1 - j0 - fp.ya;  // rows relative to the strip
         const int tx0 = i0 >> 6, tx1 = i1 >> 6, ty0 = r0 >> 5, ty1 = r1 >> 5;
         int bx0, bx1, by0, by1;
@@ -663,17 +728,17 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Bi
             for (int bx = bx0; bx <= bx1; bx++) {
                 const int b = by * fp.nbx + bx;
                 if (!fits[b]) { direct = true; continue; }
-                // tiles of this bin inside the record's tile range -> 4x4 bit mask
-                const int ax0 = max(tx0 - 4 * bx, 0), ax1 = min(tx1 - 4 * bx, 3);
-                const int ay0 = max(ty0 - 4 * by, 0), ay1 = min(ty1 - 4 * by, 3);
+                // tiles of this bin inside the record's tile range -> bit mask, bit = ay * kBinSide + ax
+                const int ax0 = max(tx0 - kBinSide * bx, 0), ax1 = min(tx1 - kBinSide * bx, kBinSide - 1);
+                const int ay0 = max(ty0 - kBinSide * by, 0), ay1 = min(ty1 - kBinSide * by, kBinSide - 1);
                 const uint32_t rowbits = ((1u << (ax1 + 1)) - 1u) & ~((1u << ax0) - 1u);
                 uint32_t m = 0;
-                for (int ay = ay0; ay <= ay1; ay++) m |= rowbits << (4 * ay);
+                for (int ay = ay0; ay <= ay1; ay++) m |= rowbits << (kBinSide * ay);
                 entries[size_t(start[b]) + base[b] + atomicAdd(&cnt[b], 1u)] = (unsigned long long)id | ((unsigned long long)m << 32);
             }
         if (direct) {  // a bin it touches has no room: resolve through the global key buffer
             Edges e;
-            edges_from_screen(r, e);
+            edges_from_screen(records[id], e);
             for (int j = j0; j <= j1; j++) {
                 const size_t row = size_t(fp.rows - 1 - j) * fp.cols;
                 for (int i = i0; i <= i1; i++) {
@@ -686,12 +751,14 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Bi
 }
 
 // Colour and depth of cell (i, j) from the winner's setup record; unclipped records take their
-// varyings from the triangle's attribute row, clipped ones are rebuilt by shade_cell.
+// varyings from the triangle's attribute row (one vertex's worth when the triangle is flat, world
+// positions only when point lights are on), clipped ones are rebuilt by shade_cell.
 __device__ __forceinline__ void shade_from_record(const FrameParams &fp, const float *__restrict__ vbo,
                                                   const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
                                                   const BinRec &rec, int i, int j, uint8_t (&px)[4], float &zw) {
-    if (rec.clipped) { shade_cell(fp, vbo, idx, rec.id, i, j, px, zw); return; }
+    if (rec.flags & kFlagClipped) { shade_cell(fp, vbo, idx, rec.id, i, j, px, zw); return; }
     const float *a = triattr + size_t(rec.id >> 1) * 27;
+    const int s1 = (rec.flags & kFlagFlat) ? 0 : 6, s2 = (rec.flags & kFlagFlat) ? 0 : 12;
     Edges e;
     edges_from_screen(rec, e);
     float f[3];
@@ -700,7 +767,13 @@ __device__ __forceinline__ void shade_from_record(const FrameParams &fp, const f
     const float b0 = f[0] * rS, b1 = f[1] * rS, b2 = f[2] * rS;
     float v[9];
 #pragma unroll
-    for (int q = 0; q < 9; q++) v[q] = (b0 * a[q] + b1 * a[9 + q]) + b2 * a[18 + q];
+    for (int q = 0; q < 6; q++) v[3 + q] = (b0 * a[q] + b1 * a[s1 + q]) + b2 * a[s2 + q];
+    if (fp.n_pl > 0) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) v[q] = (b0 * a[18 + q] + b1 * a[21 + q]) + b2 * a[24 + q];
+    } else {
+        v[0] = v[1] = v[2] = 0.0f;  // only the point-light loop reads the position
+    }
     shade(fp, v, px);
 }
 
@@ -721,8 +794,8 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
     const int tile_x = int(blockIdx.x) % fp.ntx, tile_y = int(blockIdx.x) / fp.ntx;
     const int tx0 = tile_x * kTileW, tr0 = fp.ya + tile_y * kTileH;                      // first column / output row
     const int tx1 = min(tx0 + kTileW, fp.cols) - 1, tr1 = min(tr0 + kTileH, fp.yb) - 1;  // last column / row
-    const int bin = (tile_y >> 2) * fp.nbx + (tile_x >> 2);
-    const uint32_t bit = 1u << ((tile_y & 3) * 4 + (tile_x & 3));
+    const int bin = (tile_y >> kBinShift) * fp.nbx + (tile_x >> kBinShift);
+    const uint32_t bit = 1u << ((tile_y & (kBinSide - 1)) * kBinSide + (tile_x & (kBinSide - 1)));
     const BinState &st = state[fp.frame & 1u];
     for (int c = int(tid); c < kTileCells; c += 256) keys[c] = kBackgroundKey;
     if (tid == 0) { n_list = 0; n_big = 0; n_cov = 0; }
@@ -952,7 +1025,8 @@ struct ar_ctx {
     size_t tripos_stride = 0;
     float *d_triattr = nullptr;      // n_tris x 27 floats: the three vertices' varyings
     BinRec *d_records = nullptr;     // 2 x n_tris setup records, indexed by id
-    uint32_t *d_surv = nullptr;      // per k_setup workgroup: ids of its surviving sub-triangles
+    uint8_t *d_flat = nullptr;       // n_tris flags: identical normal and colour at the three vertices
+    uint4 *d_surv = nullptr;         // per k_setup workgroup: (id, cell range, flags) of its surviving sub-triangles
     uint32_t *d_surv_count = nullptr;
     uint32_t *d_dircount = nullptr;  // per k_setup workgroup: entries per bin
     size_t group_cap = 0, dircount_cap = 0;
@@ -1078,14 +1152,14 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
     const unsigned cell_blocks = unsigned((strip_cells + 255) / 256);
     fp.ntx = (cols + kTileW - 1) / kTileW;
     fp.nty = (fp.yb - fp.ya + kTileH - 1) / kTileH;
-    fp.nbx = (fp.ntx + 3) / 4;
-    fp.nby = (fp.nty + 3) / 4;
+    fp.nbx = (fp.ntx + kBinSide - 1) / kBinSide;
+    fp.nby = (fp.nty + kBinSide - 1) / kBinSide;
     const size_t nt = size_t(fp.ntx) * fp.nty;
     const size_t nbins = size_t(fp.nbx) * fp.nby;
     const bool tiled = ctx->path == 0 && nt <= size_t(kMaxTiles) && nbins <= size_t(kMaxBins) && cols <= 65535 &&
                        rows <= 65535 && ctx->d_tripos;
     if (tiled) {
-        // k_setup workgroups take chunks of 1024..4096 consecutive triangles (1..4 per lane)
+        // k_setup workgroups take chunks of 1024..4096 consecutive triangles (1..kSetupPerLane per lane)
         uint32_t chunk = (fp.n_tris / 512u + 1023u) / 1024u * 1024u;
         chunk = chunk < 1024u ? 1024u : (chunk > 4096u ? 4096u : chunk);
         fp.chunk = chunk;
@@ -1104,7 +1178,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
             AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
             (void)hipFree(ctx->d_surv); (void)hipFree(ctx->d_surv_count);
             ctx->d_surv = nullptr; ctx->d_surv_count = nullptr; ctx->group_cap = 0;
-            AR_HIP(ctx, hipMalloc(&ctx->d_surv, want_groups * sizeof(uint32_t)));
+            AR_HIP(ctx, hipMalloc(&ctx->d_surv, want_groups * sizeof(uint4)));
             AR_HIP(ctx, hipMalloc(&ctx->d_surv_count, (want_groups / 2048 + 1) * sizeof(uint32_t)));
             ctx->group_cap = want_groups;
         }
@@ -1131,8 +1205,12 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
     if (tiled) {
         {
             Stamper s(ctx, K_SETUP);
-            k_setup<<<fp.n_groups, kSetupThreads, 0, ctx->stream>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_records, ctx->d_surv,
+            k_setup<<<fp.n_groups, kSetupThreads, 0, ctx->stream>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_flat, ctx->d_records, ctx->d_surv,
                                                                    ctx->d_surv_count, ctx->d_dircount, ctx->d_state);
+        }
+        {
+            Stamper s(ctx, K_BINSCAN);
+            k_binscan<<<unsigned((nbins + 63) / 64), 1024, 0, ctx->stream>>>(fp, ctx->d_dircount, ctx->d_state);
         }
         {
             Stamper s(ctx, K_FILL);
@@ -1225,6 +1303,7 @@ void ar_destroy(ar_ctx *ctx) {
     (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii);
     (void)hipFree(ctx->d_entries); (void)hipFree(ctx->d_state); (void)hipFree(ctx->d_surv); (void)hipFree(ctx->d_surv_count);
     (void)hipFree(ctx->d_dircount); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr); (void)hipFree(ctx->d_records);
+    (void)hipFree(ctx->d_flat);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1238,8 +1317,9 @@ int ar_set_mesh(ar_ctx *ctx, const float *vbo9, uint32_t n_verts, const uint32_t
     AR_HIP(ctx, hipSetDevice(ctx->device));
     AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr);
-    (void)hipFree(ctx->d_records);
+    (void)hipFree(ctx->d_records); (void)hipFree(ctx->d_flat);
     ctx->d_vbo = nullptr; ctx->d_idx = nullptr; ctx->d_tripos = nullptr; ctx->d_triattr = nullptr; ctx->d_records = nullptr;
+    ctx->d_flat = nullptr;
     ctx->n_verts = 0; ctx->n_tris = 0;
     if (!n_tris) return 0;
     AR_HIP(ctx, hipMalloc(&ctx->d_vbo, size_t(n_verts) * 9 * sizeof(float)));
@@ -1251,8 +1331,9 @@ int ar_set_mesh(ar_ctx *ctx, const float *vbo9, uint32_t n_verts, const uint32_t
     AR_HIP(ctx, hipMalloc(&ctx->d_tripos, 9 * ctx->tripos_stride * sizeof(float)));
     AR_HIP(ctx, hipMalloc(&ctx->d_triattr, size_t(n_tris) * 27 * sizeof(float)));
     AR_HIP(ctx, hipMalloc(&ctx->d_records, 2 * size_t(n_tris) * sizeof(BinRec)));
+    AR_HIP(ctx, hipMalloc(&ctx->d_flat, size_t(n_tris)));
     k_tristream<<<(n_tris + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_vbo, ctx->d_idx, n_verts, n_tris, ctx->tripos_stride, ctx->d_tripos,
-                                                              ctx->d_triattr);
+                                                              ctx->d_triattr, ctx->d_flat);
     AR_HIP(ctx, hipGetLastError());
     AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_verts = n_verts; ctx->n_tris = n_tris;
