@@ -522,9 +522,9 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
     return off + incl - v;
 }
 
-// Per triangle: positions -> planes pos[k*stride + t] (k = 3*vertex + axis); varyings -> attr[t*27 ..]
-// laid out (normal, colour) x 3 vertices, then position x 3 vertices (positions are only read when
-// point lights are on); flat[t] = 1 when the three normals and the three colours are identical.
+// Per triangle: positions -> planes pos[k*stride + t] (k = 3*vertex + axis); normal and colour of each
+// vertex -> attr[t*24 + 8*v ..] = (nx, ny, nz, r, g, b, 0, 0), so a vertex is one 16-byte plus one
+// 8-byte load; flat[t] = 1 when the three normals and the three colours are identical.
 // A triangle that names a vertex outside the buffer gets NaN positions, which every later stage rejects.
 __global__ __launch_bounds__(256) void k_tristream(const float *__restrict__ vbo, const uint32_t *__restrict__ idx,
                                                    uint32_t n_verts, uint32_t n_tris, size_t stride,
@@ -545,17 +545,14 @@ __global__ __launch_bounds__(256) void k_tristream(const float *__restrict__ vbo
 #pragma unroll
         for (int ax = 0; ax < 3; ax++) pos[size_t(3 * v + ax) * stride + t] = ok ? p[ax] : __builtin_nanf("");
     }
-    float *row = attr + size_t(t) * 27;
+    float4 *row = reinterpret_cast<float4 *>(attr) + size_t(t) * 6;
     bool is_flat = all_ok;
 #pragma unroll
     for (int v = 0; v < 3; v++) {
+        row[2 * v] = make_float4(a[v][3], a[v][4], a[v][5], a[v][6]);
+        row[2 * v + 1] = make_float4(a[v][7], a[v][8], 0.0f, 0.0f);
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-            row[6 * v + q] = a[v][3 + q];
-            is_flat = is_flat && (__float_as_uint(a[v][3 + q]) == __float_as_uint(a[0][3 + q]));
-        }
-#pragma unroll
-        for (int q = 0; q < 3; q++) row[18 + 3 * v + q] = a[v][q];
+        for (int q = 3; q < 9; q++) is_flat = is_flat && (__float_as_uint(a[v][q]) == __float_as_uint(a[0][q]));
     }
     flat[t] = is_flat ? 1 : 0;
 }
@@ -568,26 +565,6 @@ __device__ __forceinline__ Vert<0> transform_position(const FrameParams &fp, flo
     return o;
 }
 
-// Calls f(screen, i0, i1, j0, j1, sub, clipped) for every sub-triangle of the triangle with vertex
-// positions p[0..8] that can produce fragments in window rows [jlo, jhi]: transformed, near-clipped,
-// front facing, non-empty cell range.
-template <typename F>
-__device__ __forceinline__ void for_each_subtri(const FrameParams &fp, const float (&p)[9], int jlo, int jhi, F &&f) {
-    const Vert<0> in0 = transform_position(fp, p[0], p[1], p[2]), in1 = transform_position(fp, p[3], p[4], p[5]),
-                  in2 = transform_position(fp, p[6], p[7], p[8]);
-    Vert<0> s0[3], s1[3];
-    const int ns = clip_near<0>(in0, in1, in2, s0, s1);
-    const bool clipped = ns == 2 || (in0.c[2] + in0.c[3] < 0.0f) || (in1.c[2] + in1.c[3] < 0.0f) || (in2.c[2] + in2.c[3] < 0.0f);
-    for (int s = 0; s < ns; s++) {
-        const Vert<0> t0 = s ? s1[0] : s0[0], t1 = s ? s1[1] : s0[1], t2 = s ? s1[2] : s0[2];
-        Screen sc;
-        if (!to_screen(t0.c, t1.c, t2.c, fp.hw, fp.hh, sc) || !front_facing(sc)) continue;
-        int i0, i1, j0, j1;
-        if (!cell_range(sc.X, sc.Y, sc.W, fp.cols, jlo, jhi, i0, i1, j0, j1)) continue;
-        f(sc, i0, i1, j0, j1, s, clipped);
-    }
-}
-
 // Range of bins a cell range touches.
 __device__ __forceinline__ void bin_range(const FrameParams &fp, int i0, int i1, int j0, int j1, int &bx0, int &bx1,
                                           int &by0, int &by1) {
@@ -595,14 +572,55 @@ __device__ __forceinline__ void bin_range(const FrameParams &fp, int i0, int i1,
     by0 = (fp.rows - 1 - j1 - fp.ya) >> (5 + kBinShift); by1 = (fp.rows - 1 - j0 - fp.ya) >> (5 + kBinShift);
 }
 
-// surv: per workgroup a list of (id, i0 | i1 << 16, j0 | j1 << 16, flags) for its surviving sub-triangles.
+// One sub-triangle that survived setup: screen-space vertices and inclusive cell range.
+struct Candidate {
+    Screen sc;
+    int i0, i1, j0, j1;
+};
+
+// Setup of the triangle with vertex positions p[0..8]: transform, near clip, cull, cell range within
+// window rows [jlo, jhi].  c[s] / have[s] describe sub-triangle s; clipped tells whether the near
+// plane cut the triangle.
+__device__ __forceinline__ void triangle_setup(const FrameParams &fp, const float (&p)[9], int jlo, int jhi,
+                                               Candidate (&c)[2], bool (&have)[2], bool &clipped) {
+    const Vert<0> in0 = transform_position(fp, p[0], p[1], p[2]), in1 = transform_position(fp, p[3], p[4], p[5]),
+                  in2 = transform_position(fp, p[6], p[7], p[8]);
+    Vert<0> s0[3], s1[3];
+    const int ns = clip_near<0>(in0, in1, in2, s0, s1);
+    clipped = ns == 2 || (in0.c[2] + in0.c[3] < 0.0f) || (in1.c[2] + in1.c[3] < 0.0f) || (in2.c[2] + in2.c[3] < 0.0f);
+    have[0] = have[1] = false;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        if (s >= ns) continue;
+        const Vert<0> t0 = s ? s1[0] : s0[0], t1 = s ? s1[1] : s0[1], t2 = s ? s1[2] : s0[2];
+        if (!to_screen(t0.c, t1.c, t2.c, fp.hw, fp.hh, c[s].sc) || !front_facing(c[s].sc)) continue;
+        have[s] = cell_range(c[s].sc.X, c[s].sc.Y, c[s].sc.W, fp.cols, jlo, jhi, c[s].i0, c[s].i1, c[s].j0, c[s].j1);
+    }
+}
+
+__device__ __forceinline__ BinRec make_record(const Candidate &c, uint32_t id, uint32_t flags) {
+    BinRec r;
+#pragma unroll
+    for (int q = 0; q < 3; q++) { r.X[q] = c.sc.X[q]; r.Y[q] = c.sc.Y[q]; r.W[q] = c.sc.W[q]; r.Z[q] = c.sc.Z[q]; }
+    r.id = id;
+    r.i0 = uint16_t(c.i0); r.i1 = uint16_t(c.i1); r.j0 = uint16_t(c.j0); r.j1 = uint16_t(c.j1);
+    r.flags = flags;
+    return r;
+}
+
+// Workgroup g owns record slots [g * 2 * chunk, (g + 1) * 2 * chunk) and fills them densely, in
+// triangle order: a record's slot number ("loc") therefore grows with its id, and visibility keys
+// carry loc in place of the id - same tie-break, and the winner's record is found without a lookup.
+// surv: the same slots as (id, i0 | i1 << 16, j0 | j1 << 16, flags) tuples for k_fill.
 __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const float *__restrict__ tripos, size_t stride,
                                                          const uint8_t *__restrict__ flat, BinRec *__restrict__ records,
                                                          uint4 *__restrict__ surv, uint32_t *__restrict__ surv_count,
                                                          uint32_t *__restrict__ dircount, BinState *__restrict__ state) {
     __shared__ uint32_t hist[kMaxBins];
-    __shared__ uint32_t n_surv;
-    const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t s_wave[kSetupThreads / 64];
+    __shared__ uint4 stage[kSetupThreads / 64][64 * 4];  // per wavefront: 64 records as 16-byte pieces
+    __shared__ uint32_t stage_dst[kSetupThreads / 64][64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const int nbins = fp.nbx * fp.nby;
     const uint32_t t_begin = blockIdx.x * fp.chunk;
     const uint32_t t_end = min(t_begin + fp.chunk, fp.n_tris);
@@ -619,36 +637,60 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const f
         fl[k] = flat[tt] ? kFlagFlat : 0u;
     }
     for (int k = int(tid); k < nbins; k += kSetupThreads) hist[k] = 0;
-    if (tid == 0) n_surv = 0;
     BinState &st_next = state[(fp.frame + 1u) & 1u];
     if (blockIdx.x == 0 && tid == 0) { st_next.overflow = 0; st_next.n_entries = 0; }  // idle values for the next frame
     __syncthreads();
     const int jlo = fp.rows - fp.yb, jhi = fp.rows - 1 - fp.ya;
-    uint4 *my_surv = surv + size_t(blockIdx.x) * 2 * fp.chunk;
+    const uint32_t loc_base = blockIdx.x * 2u * fp.chunk;
+    uint32_t run = 0;  // slots handed out so far (identical in every lane)
 
 #pragma unroll
     for (int k = 0; k < kSetupPerLane; k++) {
         const uint32_t t = t_begin + tid + uint32_t(k) * kSetupThreads;
-        if (!(t < t_end && uint32_t(k) * kSetupThreads < fp.chunk)) continue;
-        for_each_subtri(fp, p[k], jlo, jhi, [&](const Screen &sc, int i0, int i1, int j0, int j1, int sub, bool clipped) {
-            BinRec r;
+        const bool live = t < t_end && uint32_t(k) * kSetupThreads < fp.chunk;
+        Candidate c[2];
+        bool have[2] = {false, false}, clipped = false;
+        if (live) triangle_setup(fp, p[k], jlo, jhi, c, have, clipped);
+        uint32_t total;
+        const uint32_t slot = run + block_exclusive_scan<kSetupThreads / 64>(uint32_t(have[0]) + uint32_t(have[1]), s_wave, total);
+        run += total;
+        const uint32_t flags = (clipped ? kFlagClipped : 0u) | fl[k];
+        // sub-triangle 0 goes through the wavefront's LDS stage so that the 64-byte records leave as
+        // contiguous 16-byte pieces; the rare second sub-triangle is stored directly
+        const unsigned long long m0 = __ballot(have[0]);
+        const uint32_t rank = uint32_t(__popcll(m0 & ((1ull << lane) - 1ull)));
+        if (have[0]) {
+            const BinRec r = make_record(c[0], 2u * t, flags);
+            const uint4 *src = reinterpret_cast<const uint4 *>(&r);
 #pragma unroll
-            for (int q = 0; q < 3; q++) { r.X[q] = sc.X[q]; r.Y[q] = sc.Y[q]; r.W[q] = sc.W[q]; r.Z[q] = sc.Z[q]; }
-            r.id = 2u * t + uint32_t(sub);
-            r.i0 = uint16_t(i0); r.i1 = uint16_t(i1); r.j0 = uint16_t(j0); r.j1 = uint16_t(j1);
-            r.flags = (clipped ? kFlagClipped : 0u) | fl[k];
-            records[r.id] = r;
-            my_surv[atomicAdd(&n_surv, 1u)] = make_uint4(r.id, uint32_t(i0) | (uint32_t(i1) << 16),
-                                                         uint32_t(j0) | (uint32_t(j1) << 16), r.flags);
+            for (int q = 0; q < 4; q++) stage[wave][rank * 4 + q] = src[q];
+            stage_dst[wave][rank] = loc_base + slot;
+            surv[loc_base + slot] = make_uint4(r.id, uint32_t(c[0].i0) | (uint32_t(c[0].i1) << 16),
+                                               uint32_t(c[0].j0) | (uint32_t(c[0].j1) << 16), flags);
+        }
+        if (have[1]) {
+            const uint32_t loc1 = loc_base + slot + (have[0] ? 1u : 0u);
+            const BinRec r = make_record(c[1], 2u * t + 1u, flags);
+            records[loc1] = r;
+            surv[loc1] = make_uint4(r.id, uint32_t(c[1].i0) | (uint32_t(c[1].i1) << 16),
+                                    uint32_t(c[1].j0) | (uint32_t(c[1].j1) << 16), flags);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            if (!have[s]) continue;
             int bx0, bx1, by0, by1;
-            bin_range(fp, i0, i1, j0, j1, bx0, bx1, by0, by1);
+            bin_range(fp, c[s].i0, c[s].i1, c[s].j0, c[s].j1, bx0, bx1, by0, by1);
             for (int by = by0; by <= by1; by++)
                 for (int bx = bx0; bx <= bx1; bx++) atomicAdd(&hist[by * fp.nbx + bx], 1u);
-        });
+        }
+        __syncthreads();
+        const uint32_t n0 = uint32_t(__popcll(m0));
+        for (uint32_t q = lane; q < n0 * 4u; q += 64u)
+            reinterpret_cast<uint4 *>(records + stage_dst[wave][q >> 2])[q & 3u] = stage[wave][q];
     }
     __syncthreads();
     for (int k = int(tid); k < nbins; k += kSetupThreads) dircount[size_t(blockIdx.x) * nbins + k] = hist[k];
-    if (tid == 0) surv_count[blockIdx.x] = n_surv;
+    if (tid == 0) surv_count[blockIdx.x] = run;
 }
 
 // Column-wise exclusive prefix over the k_setup workgroups of the count table, in place: afterwards
@@ -664,7 +706,13 @@ __global__ __launch_bounds__(1024) void k_binscan(FrameParams fp, uint32_t *__re
     const uint32_t g0 = min(uint32_t(rg) * rows_per, fp.n_groups), g1 = min(g0 + rows_per, fp.n_groups);
     uint32_t sum = 0;
     if (b < nbins)
-        for (uint32_t g = g0; g < g1; g++) sum += table[size_t(g) * nbins + b];
+        for (uint32_t gb = g0; gb < g1; gb += 16) {  // 16 independent loads in flight per step
+            uint32_t v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = (gb + k < g1) ? table[size_t(gb + k) * nbins + b] : 0u;
+#pragma unroll
+            for (int k = 0; k < 16; k++) sum += v[k];
+        }
     part[rg][lane] = sum;
     __syncthreads();
     uint32_t run = 0, tot = 0;
@@ -675,10 +723,15 @@ __global__ __launch_bounds__(1024) void k_binscan(FrameParams fp, uint32_t *__re
         tot += x;
     }
     if (b < nbins) {
-        for (uint32_t g = g0; g < g1; g++) {
-            const uint32_t v = table[size_t(g) * nbins + b];
-            table[size_t(g) * nbins + b] = run;
-            run += v;
+        for (uint32_t gb = g0; gb < g1; gb += 16) {
+            uint32_t v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = (gb + k < g1) ? table[size_t(gb + k) * nbins + b] : 0u;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (gb + k < g1) table[size_t(gb + k) * nbins + b] = run;
+                run += v[k];
+            }
         }
         if (rg == 0) state[fp.frame & 1u].total[b] = tot;
     }
@@ -714,10 +767,10 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Bi
         if (tid == 0) st.n_entries = n_entries;
     }
     __syncthreads();
-    const uint4 *my_surv = surv + size_t(blockIdx.x) * 2 * fp.chunk;
+    const uint32_t loc_base = blockIdx.x * 2u * fp.chunk;
     for (uint32_t s = tid; s < n; s += kSetupThreads) {
-        const uint4 sv = my_surv[s];
-        const uint32_t id = sv.x;
+        const uint32_t loc = loc_base + s;  // record slot; also what the visibility keys carry
+        const uint4 sv = surv[loc];
         const int i0 = int(sv.y & 0xFFFFu), i1 = int(sv.y >> 16), j0 = int(sv.z & 0xFFFFu), j1 = int(sv.z >> 16);
         const int r0 = fp.rows - 1 - j1 - fp.ya, r1 = fp.rows - 1 - j0 - fp.ya;  // rows relative to the strip
         const int tx0 = i0 >> 6, tx1 = i1 >> 6, ty0 = r0 >> 5, ty1 = r1 >> 5;
@@ -734,31 +787,37 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Bi
                 const uint32_t rowbits = ((1u << (ax1 + 1)) - 1u) & ~((1u << ax0) - 1u);
                 uint32_t m = 0;
                 for (int ay = ay0; ay <= ay1; ay++) m |= rowbits << (kBinSide * ay);
-                entries[size_t(start[b]) + base[b] + atomicAdd(&cnt[b], 1u)] = (unsigned long long)id | ((unsigned long long)m << 32);
+                entries[size_t(start[b]) + base[b] + atomicAdd(&cnt[b], 1u)] = (unsigned long long)loc | ((unsigned long long)m << 32);
             }
         if (direct) {  // a bin it touches has no room: resolve through the global key buffer
             Edges e;
-            edges_from_screen(records[id], e);
+            edges_from_screen(records[loc], e);
             for (int j = j0; j <= j1; j++) {
                 const size_t row = size_t(fp.rows - 1 - j) * fp.cols;
                 for (int i = i0; i <= i1; i++) {
                     float f[3], zw;
-                    if (cover(e, i, j, f, zw)) vis_min(vis, row + i, make_key(zw, id));
+                    if (cover(e, i, j, f, zw)) vis_min(vis, row + i, make_key(zw, loc));
                 }
             }
         }
     }
 }
 
-// Colour and depth of cell (i, j) from the winner's setup record; unclipped records take their
-// varyings from the triangle's attribute row (one vertex's worth when the triangle is flat, world
-// positions only when point lights are on), clipped ones are rebuilt by shade_cell.
+// Colour and depth of cell (i, j) from the winner's setup record; unclipped records take normal and
+// colour from the triangle's attribute row (one vertex's worth when the triangle is flat) and world
+// positions from the position planes (only when point lights are on); clipped ones are rebuilt by
+// shade_cell.
 __device__ __forceinline__ void shade_from_record(const FrameParams &fp, const float *__restrict__ vbo,
                                                   const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
-                                                  const BinRec &rec, int i, int j, uint8_t (&px)[4], float &zw) {
+                                                  const float *__restrict__ tripos, size_t stride, const BinRec &rec,
+                                                  int i, int j, uint8_t (&px)[4], float &zw) {
     if (rec.flags & kFlagClipped) { shade_cell(fp, vbo, idx, rec.id, i, j, px, zw); return; }
-    const float *a = triattr + size_t(rec.id >> 1) * 27;
-    const int s1 = (rec.flags & kFlagFlat) ? 0 : 6, s2 = (rec.flags & kFlagFlat) ? 0 : 12;
+    const uint32_t t = rec.id >> 1;
+    const float4 *row = reinterpret_cast<const float4 *>(triattr) + size_t(t) * 6;
+    const int o1 = (rec.flags & kFlagFlat) ? 0 : 2, o2 = (rec.flags & kFlagFlat) ? 0 : 4;
+    const float4 a0 = row[0], a1 = row[o1], a2 = row[o2];
+    const float2 c0 = *reinterpret_cast<const float2 *>(row + 1), c1 = *reinterpret_cast<const float2 *>(row + o1 + 1),
+                 c2 = *reinterpret_cast<const float2 *>(row + o2 + 1);
     Edges e;
     edges_from_screen(rec, e);
     float f[3];
@@ -766,11 +825,18 @@ __device__ __forceinline__ void shade_from_record(const FrameParams &fp, const f
     const float rS = 1.0f / ((f[0] + f[1]) + f[2]);
     const float b0 = f[0] * rS, b1 = f[1] * rS, b2 = f[2] * rS;
     float v[9];
-#pragma unroll
-    for (int q = 0; q < 6; q++) v[3 + q] = (b0 * a[q] + b1 * a[s1 + q]) + b2 * a[s2 + q];
+    v[3] = (b0 * a0.x + b1 * a1.x) + b2 * a2.x;
+    v[4] = (b0 * a0.y + b1 * a1.y) + b2 * a2.y;
+    v[5] = (b0 * a0.z + b1 * a1.z) + b2 * a2.z;
+    v[6] = (b0 * a0.w + b1 * a1.w) + b2 * a2.w;
+    v[7] = (b0 * c0.x + b1 * c1.x) + b2 * c2.x;
+    v[8] = (b0 * c0.y + b1 * c1.y) + b2 * c2.y;
     if (fp.n_pl > 0) {
+        float p[9];
 #pragma unroll
-        for (int q = 0; q < 3; q++) v[q] = (b0 * a[18 + q] + b1 * a[21 + q]) + b2 * a[24 + q];
+        for (int q = 0; q < 9; q++) p[q] = tripos[size_t(q) * stride + t];
+#pragma unroll
+        for (int q = 0; q < 3; q++) v[q] = (b0 * p[q] + b1 * p[3 + q]) + b2 * p[6 + q];
     } else {
         v[0] = v[1] = v[2] = 0.0f;  // only the point-light loop reads the position
     }
@@ -779,6 +845,7 @@ __device__ __forceinline__ void shade_from_record(const FrameParams &fp, const f
 
 __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__restrict__ vbo,
                                               const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
+                                              const float *__restrict__ tripos, size_t stride,
                                               const BinRec *__restrict__ records,
                                               const unsigned long long *__restrict__ entries, uint32_t entries_cap,
                                               const BinState *__restrict__ state, uint64_t *__restrict__ vis,
@@ -819,13 +886,13 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
         if (nl + 256 > uint32_t(kTileListMax) || last) {
             // records with a small cell range inside the tile: one lane each; others -> sweep list
             for (uint32_t r = tid; r < nl; r += 256) {
-                const uint32_t id = list[r];
-                const BinRec rec = records[id];
+                const uint32_t loc = list[r];
+                const BinRec rec = records[loc];
                 const int i0 = max(int(rec.i0), tx0), i1 = min(int(rec.i1), tx1);
                 const int r0 = max(fp.rows - 1 - int(rec.j1), tr0), r1 = min(fp.rows - 1 - int(rec.j0), tr1);
                 if ((i1 - i0 + 1) * (r1 - r0 + 1) > kTileSmallCells) {
                     const uint32_t slot = atomicAdd(&n_big, 1u);
-                    if (slot < uint32_t(kTileBigMax)) { big[slot] = id; continue; }
+                    if (slot < uint32_t(kTileBigMax)) { big[slot] = loc; continue; }
                     // list full: this lane scans the range itself (slow but correct)
                 }
                 Edges ed;
@@ -836,7 +903,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
                         float f[3], zw;
                         if (cover(ed, i, j, f, zw))
                             atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
-                                      (unsigned long long)make_key(zw, id));
+                                      (unsigned long long)make_key(zw, loc));
                     }
                 }
             }
@@ -844,7 +911,8 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
             // sweep list: all lanes cover one record's cell range, 256 cells per step
             const uint32_t nb = min(n_big, uint32_t(kTileBigMax));
             for (uint32_t b = 0; b < nb; b++) {
-                const BinRec rec = records[big[b]];
+                const uint32_t loc = big[b];
+                const BinRec rec = records[loc];
                 const int i0 = max(int(rec.i0), tx0), i1 = min(int(rec.i1), tx1);
                 const int r0 = max(fp.rows - 1 - int(rec.j1), tr0), r1 = min(fp.rows - 1 - int(rec.j0), tr1);
                 const int w = i1 - i0 + 1, n = w * (r1 - r0 + 1);
@@ -855,7 +923,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
                     float f[3], zw;
                     if (cover(ed, i, fp.rows - 1 - rr, f, zw))
                         atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
-                                  (unsigned long long)make_key(zw, rec.id));
+                                  (unsigned long long)make_key(zw, loc));
                 }
             }
             __syncthreads();
@@ -888,11 +956,11 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
     for (uint32_t k = tid; k < nc; k += 256) {
         const int c = int(covered[k]);
         const int rr = tr0 + (c >> 6), i = tx0 + (c & 63);
-        const uint32_t id = uint32_t(keys[c]);
+        const BinRec rec = records[uint32_t(keys[c])];  // the key's low word is the winner's record slot
         uint8_t px[4];
         float zw;
-        shade_from_record(fp, vbo, idx, triattr, records[id], i, fp.rows - 1 - rr, px, zw);
-        if (fp.want_ids) ids[size_t(rr) * fp.cols + i] = id;
+        shade_from_record(fp, vbo, idx, triattr, tripos, stride, rec, i, fp.rows - 1 - rr, px, zw);
+        if (fp.want_ids) ids[size_t(rr) * fp.cols + i] = rec.id;
         keys[c] = (uint64_t(__float_as_uint(zw)) << 32) |
                   (uint32_t(px[0]) | (uint32_t(px[1]) << 8) | (uint32_t(px[2]) << 16) | (uint32_t(px[3]) << 24));
     }
@@ -1023,8 +1091,8 @@ struct ar_ctx {
     uint32_t pool_cap_option = 0;    // 0: sized from the triangle count
     float *d_tripos = nullptr;       // 9 planes x tripos_stride floats: triangle positions
     size_t tripos_stride = 0;
-    float *d_triattr = nullptr;      // n_tris x 27 floats: the three vertices' varyings
-    BinRec *d_records = nullptr;     // 2 x n_tris setup records, indexed by id
+    float *d_triattr = nullptr;      // n_tris x 24 floats: the three vertices' normals and colours
+    BinRec *d_records = nullptr;     // 2 x n_tris setup record slots, filled densely per k_setup workgroup
     uint8_t *d_flat = nullptr;       // n_tris flags: identical normal and colour at the three vertices
     uint4 *d_surv = nullptr;         // per k_setup workgroup: (id, cell range, flags) of its surviving sub-triangles
     uint32_t *d_surv_count = nullptr;
@@ -1219,7 +1287,8 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
         }
         {
             Stamper s(ctx, K_TILE);
-            k_tile<<<unsigned(nt), 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_records, ctx->d_entries,
+            k_tile<<<unsigned(nt), 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_tripos, ctx->tripos_stride,
+                                                         ctx->d_records, ctx->d_entries,
                                                          ctx->pool_cap, ctx->d_state, ctx->d_vis, ctx->d_rgba, ctx->d_depth,
                                                          ctx->d_ascii, ctx->d_ridx, ctx->d_ids);
         }
@@ -1329,7 +1398,7 @@ int ar_set_mesh(ar_ctx *ctx, const float *vbo9, uint32_t n_verts, const uint32_t
     // derived, position-only stream for the binning pass and the per-id record store of the tiled path
     ctx->tripos_stride = (size_t(n_tris) + 63) / 64 * 64;
     AR_HIP(ctx, hipMalloc(&ctx->d_tripos, 9 * ctx->tripos_stride * sizeof(float)));
-    AR_HIP(ctx, hipMalloc(&ctx->d_triattr, size_t(n_tris) * 27 * sizeof(float)));
+    AR_HIP(ctx, hipMalloc(&ctx->d_triattr, size_t(n_tris) * 24 * sizeof(float)));
     AR_HIP(ctx, hipMalloc(&ctx->d_records, 2 * size_t(n_tris) * sizeof(BinRec)));
     AR_HIP(ctx, hipMalloc(&ctx->d_flat, size_t(n_tris)));
     k_tristream<<<(n_tris + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_vbo, ctx->d_idx, n_verts, n_tris, ctx->tripos_stride, ctx->d_tripos,
