@@ -35,10 +35,10 @@ constexpr int kMediumMaxCells = 4096;   // above this a record goes to the per-c
 constexpr uint32_t kMediumCapacity = 1u << 18;
 constexpr uint32_t kLargeCapacity = 1u << 14;
 
-enum KernelSlot { K_CLEAR = 0, K_RASTER, K_MEDIUM, K_LARGE, K_SHADE, K_ASCII, K_SETUP, K_BINSCAN, K_FILL, K_TILE };
+enum KernelSlot { K_CLEAR = 0, K_RASTER, K_MEDIUM, K_LARGE, K_SHADE, K_ASCII, K_SETUP, K_BINSCAN, K_BINOFF, K_FILL, K_TILE };
 const char *const kKernelNames[AR_N_KERNELS] = {"k_clear",  "k_raster", "k_raster_medium", "k_raster_large",
                                                 "k_shade", "k_ascii",  "k_setup",         "k_binscan",
-                                                "k_fill",  "k_tile"};
+                                                "k_binoffsets", "k_fill", "k_tile"};
 
 // Everything a frame's kernels need besides the big buffers; passed by value as a kernel argument.
 struct FrameParams {
@@ -454,9 +454,9 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__re
 //   k_binscan column-wise exclusive prefix of the count table over the k_setup workgroups (in place)
 //             and the bin totals: every (workgroup, bin) pair gets a fixed slice of the bin's entry
 //             array without a single global atomic.
-//   k_fill    exclusive scan of the bin totals -> start of each bin's entry array; every workgroup
-//             writes one entry (id, mask of the bin's tiles the cell range touches) per (survivor,
-//             bin) into its slices.
+//   k_binoffsets  bin totals, start of each bin's entry array (exclusive scan), row-block offsets.
+//   k_fill    every k_setup workgroup's survivors become one entry (record slot, mask of the bin's
+//             tiles the cell range touches) per (survivor, bin), written into that workgroup's slice.
 //   k_tile    one workgroup per tile: filters its bin's entries by mask bit into an LDS work list,
 //             rasterises those records into a 2048-entry LDS key tile with LDS atomic min (small
 //             cell ranges: one lane per record; large ones: all lanes sweep the range), then shades
@@ -471,8 +471,8 @@ constexpr int kBinShift = 1;          // a bin is 2x2 tiles = 128x64 cells
 constexpr int kBinSide = 1 << kBinShift;
 constexpr int kMaxTiles = 8000;       // tiles per frame the tiled path accepts
 constexpr int kMaxBins = 2048;        // >= kMaxTiles / 4 for any tile-grid shape the path accepts
-constexpr int kSetupThreads = 1024;   // k_setup / k_fill workgroup size
-constexpr int kSetupPerLane = 4;      // triangles per lane of k_setup (chunk <= 4096)
+constexpr int kSetupThreads = 256;    // k_setup / k_fill workgroup size
+constexpr uint32_t kMaxGroups = 4096;  // k_setup workgroups (rows of the count table)
 constexpr int kTileBigMax = 512;      // per-tile list of records swept cooperatively
 constexpr int kTileSmallCells = 64;   // cell-range area (inside the tile) one lane scans itself
 constexpr int kTileListMax = 2048;    // ids staged in LDS between the filter and the raster step
@@ -612,30 +612,18 @@ __device__ __forceinline__ BinRec make_record(const Candidate &c, uint32_t id, u
 // triangle order: a record's slot number ("loc") therefore grows with its id, and visibility keys
 // carry loc in place of the id - same tie-break, and the winner's record is found without a lookup.
 // surv: the same slots as (id, i0 | i1 << 16, j0 | j1 << 16, flags) tuples for k_fill.
+// One triangle per lane and pass; chunk is a multiple of the workgroup size (one pass up to about
+// four million triangles).
 __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const float *__restrict__ tripos, size_t stride,
                                                          const uint8_t *__restrict__ flat, BinRec *__restrict__ records,
                                                          uint4 *__restrict__ surv, uint32_t *__restrict__ surv_count,
                                                          uint32_t *__restrict__ dircount, BinState *__restrict__ state) {
     __shared__ uint32_t hist[kMaxBins];
     __shared__ uint32_t s_wave[kSetupThreads / 64];
-    __shared__ uint4 stage[kSetupThreads / 64][64 * 4];  // per wavefront: 64 records as 16-byte pieces
-    __shared__ uint32_t stage_dst[kSetupThreads / 64][64];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x;
     const int nbins = fp.nbx * fp.nby;
     const uint32_t t_begin = blockIdx.x * fp.chunk;
     const uint32_t t_end = min(t_begin + fp.chunk, fp.n_tris);
-    // all of this lane's triangles are fetched before the first one is processed
-    float p[kSetupPerLane][9];
-    uint32_t fl[kSetupPerLane];
-#pragma unroll
-    for (int k = 0; k < kSetupPerLane; k++) {
-        const uint32_t t = t_begin + tid + uint32_t(k) * kSetupThreads;
-        const bool live = t < t_end && uint32_t(k) * kSetupThreads < fp.chunk;
-        const uint32_t tt = live ? t : t_begin;
-#pragma unroll
-        for (int q = 0; q < 9; q++) p[k][q] = tripos[size_t(q) * stride + tt];
-        fl[k] = flat[tt] ? kFlagFlat : 0u;
-    }
     for (int k = int(tid); k < nbins; k += kSetupThreads) hist[k] = 0;
     BinState &st_next = state[(fp.frame + 1u) & 1u];
     if (blockIdx.x == 0 && tid == 0) { st_next.overflow = 0; st_next.n_entries = 0; }  // idle values for the next frame
@@ -644,127 +632,137 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const f
     const uint32_t loc_base = blockIdx.x * 2u * fp.chunk;
     uint32_t run = 0;  // slots handed out so far (identical in every lane)
 
-#pragma unroll
-    for (int k = 0; k < kSetupPerLane; k++) {
-        const uint32_t t = t_begin + tid + uint32_t(k) * kSetupThreads;
-        const bool live = t < t_end && uint32_t(k) * kSetupThreads < fp.chunk;
+    for (uint32_t tb = t_begin; tb < t_end; tb += kSetupThreads) {
+        const uint32_t t = tb + tid;
+        const bool live = t < t_end;
         Candidate c[2];
         bool have[2] = {false, false}, clipped = false;
-        if (live) triangle_setup(fp, p[k], jlo, jhi, c, have, clipped);
-        uint32_t total;
-        const uint32_t slot = run + block_exclusive_scan<kSetupThreads / 64>(uint32_t(have[0]) + uint32_t(have[1]), s_wave, total);
-        run += total;
-        const uint32_t flags = (clipped ? kFlagClipped : 0u) | fl[k];
-        // sub-triangle 0 goes through the wavefront's LDS stage so that the 64-byte records leave as
-        // contiguous 16-byte pieces; the rare second sub-triangle is stored directly
-        const unsigned long long m0 = __ballot(have[0]);
-        const uint32_t rank = uint32_t(__popcll(m0 & ((1ull << lane) - 1ull)));
-        if (have[0]) {
-            const BinRec r = make_record(c[0], 2u * t, flags);
-            const uint4 *src = reinterpret_cast<const uint4 *>(&r);
+        uint32_t flags = 0;
+        if (live) {
+            float p[9];
 #pragma unroll
-            for (int q = 0; q < 4; q++) stage[wave][rank * 4 + q] = src[q];
-            stage_dst[wave][rank] = loc_base + slot;
-            surv[loc_base + slot] = make_uint4(r.id, uint32_t(c[0].i0) | (uint32_t(c[0].i1) << 16),
-                                               uint32_t(c[0].j0) | (uint32_t(c[0].j1) << 16), flags);
+            for (int q = 0; q < 9; q++) p[q] = tripos[size_t(q) * stride + t];
+            flags = flat[t] ? kFlagFlat : 0u;
+            triangle_setup(fp, p, jlo, jhi, c, have, clipped);
+            if (clipped) flags |= kFlagClipped;
         }
-        if (have[1]) {
-            const uint32_t loc1 = loc_base + slot + (have[0] ? 1u : 0u);
-            const BinRec r = make_record(c[1], 2u * t + 1u, flags);
-            records[loc1] = r;
-            surv[loc1] = make_uint4(r.id, uint32_t(c[1].i0) | (uint32_t(c[1].i1) << 16),
-                                    uint32_t(c[1].j0) | (uint32_t(c[1].j1) << 16), flags);
-        }
+        uint32_t total;
+        uint32_t slot = run + block_exclusive_scan<kSetupThreads / 64>(uint32_t(have[0]) + uint32_t(have[1]), s_wave, total);
+        run += total;
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             if (!have[s]) continue;
+            const uint32_t loc = loc_base + slot;
+            slot++;
+            records[loc] = make_record(c[s], 2u * t + uint32_t(s), flags);
+            surv[loc] = make_uint4(2u * t + uint32_t(s), uint32_t(c[s].i0) | (uint32_t(c[s].i1) << 16),
+                                   uint32_t(c[s].j0) | (uint32_t(c[s].j1) << 16), flags);
             int bx0, bx1, by0, by1;
             bin_range(fp, c[s].i0, c[s].i1, c[s].j0, c[s].j1, bx0, bx1, by0, by1);
             for (int by = by0; by <= by1; by++)
                 for (int bx = bx0; bx <= bx1; bx++) atomicAdd(&hist[by * fp.nbx + bx], 1u);
         }
-        __syncthreads();
-        const uint32_t n0 = uint32_t(__popcll(m0));
-        for (uint32_t q = lane; q < n0 * 4u; q += 64u)
-            reinterpret_cast<uint4 *>(records + stage_dst[wave][q >> 2])[q & 3u] = stage[wave][q];
     }
     __syncthreads();
     for (int k = int(tid); k < nbins; k += kSetupThreads) dircount[size_t(blockIdx.x) * nbins + k] = hist[k];
     if (tid == 0) surv_count[blockIdx.x] = run;
 }
 
-// Column-wise exclusive prefix over the k_setup workgroups of the count table, in place: afterwards
-// table[g][b] = entries of bin b that belong to workgroups before g, and total[b] = all of them.
-// One workgroup per 64 bins; its 16 wavefronts split the rows, so no global atomics are needed and
-// the layout of every bin's entry array is the same on every run.
-__global__ __launch_bounds__(1024) void k_binscan(FrameParams fp, uint32_t *__restrict__ table, BinState *__restrict__ state) {
+// Column-wise exclusive prefix of the count table over the k_setup workgroups, in two levels.  The
+// table's rows are cut into 16 row blocks; workgroup (x, y) takes bins [64x, 64x + 64) of row block y
+// (its 16 wavefronts split the block's rows), rewrites table[g][b] as "entries of bin b that belong to
+// earlier workgroups of the same row block" and stores the block's total in blocksum[y][b].  k_fill
+// adds the totals of the earlier row blocks.  No global atomics, and the layout of every bin's entry
+// array is the same on every run.
+__global__ __launch_bounds__(1024) void k_binscan(FrameParams fp, uint32_t *__restrict__ table, uint32_t *__restrict__ blocksum) {
     __shared__ uint32_t part[16][64];
     const int nbins = fp.nbx * fp.nby;
-    const int lane = int(threadIdx.x & 63u), rg = int(threadIdx.x >> 6);
+    const int lane = int(threadIdx.x & 63u), w = int(threadIdx.x >> 6);
     const int b = int(blockIdx.x) * 64 + lane;
-    const uint32_t rows_per = (fp.n_groups + 15u) / 16u;
-    const uint32_t g0 = min(uint32_t(rg) * rows_per, fp.n_groups), g1 = min(g0 + rows_per, fp.n_groups);
-    uint32_t sum = 0;
-    if (b < nbins)
-        for (uint32_t gb = g0; gb < g1; gb += 16) {  // 16 independent loads in flight per step
-            uint32_t v[16];
+    const uint32_t rows_per_block = (fp.n_groups + 15u) / 16u;
+    const uint32_t blk0 = min(uint32_t(blockIdx.y) * rows_per_block, fp.n_groups), blk1 = min(blk0 + rows_per_block, fp.n_groups);
+    const uint32_t rows_per_wave = (rows_per_block + 15u) / 16u;  // <= 16 (at most 4096 k_setup workgroups)
+    const uint32_t g0 = min(blk0 + uint32_t(w) * rows_per_wave, blk1), g1 = min(g0 + rows_per_wave, blk1);
+    uint32_t v[16], sum = 0;
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = (gb + k < g1) ? table[size_t(gb + k) * nbins + b] : 0u;
-#pragma unroll
-            for (int k = 0; k < 16; k++) sum += v[k];
-        }
-    part[rg][lane] = sum;
+    for (int k = 0; k < 16; k++) {
+        v[k] = (b < nbins && g0 + k < g1) ? table[size_t(g0 + k) * nbins + b] : 0u;
+        sum += v[k];
+    }
+    part[w][lane] = sum;
     __syncthreads();
     uint32_t run = 0, tot = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const uint32_t x = part[k][lane];
-        if (k < rg) run += x;
+        if (k < w) run += x;
         tot += x;
     }
     if (b < nbins) {
-        for (uint32_t gb = g0; gb < g1; gb += 16) {
-            uint32_t v[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = (gb + k < g1) ? table[size_t(gb + k) * nbins + b] : 0u;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                if (gb + k < g1) table[size_t(gb + k) * nbins + b] = run;
-                run += v[k];
-            }
+        for (int k = 0; k < 16; k++) {
+            if (g0 + k < g1) table[size_t(g0 + k) * nbins + b] = run;
+            run += v[k];
         }
-        if (rg == 0) state[fp.frame & 1u].total[b] = tot;
+        if (w == 0) blocksum[size_t(blockIdx.y) * nbins + b] = tot;
     }
+}
+
+// One workgroup: per bin, exclusive prefix of the 16 row-block totals and the bin's total; an
+// exclusive scan of the totals gives the start of each bin's entry array.  boff[y][b] = start of
+// bin b + entries of row blocks before y, so that k_fill only adds its own scanned table entry.
+__global__ __launch_bounds__(1024) void k_binoffsets(FrameParams fp, const uint32_t *__restrict__ blocksum,
+                                                     uint32_t *__restrict__ boff, BinState *__restrict__ state,
+                                                     uint32_t entries_cap) {
+    __shared__ uint32_t s_wave[16];
+    const int nbins = fp.nbx * fp.nby;
+    const uint32_t tid = threadIdx.x;
+    BinState &st = state[fp.frame & 1u];
+    const int b0 = 2 * int(tid), b1 = b0 + 1;  // kMaxBins == 2 * 1024
+    uint32_t x0[16], x1[16], t0 = 0, t1 = 0;
+#pragma unroll
+    for (int y = 0; y < 16; y++) {
+        x0[y] = b0 < nbins ? blocksum[size_t(y) * nbins + b0] : 0u;
+        x1[y] = b1 < nbins ? blocksum[size_t(y) * nbins + b1] : 0u;
+        t0 += x0[y]; t1 += x1[y];
+    }
+    uint32_t n_entries;
+    const uint32_t s0 = block_exclusive_scan<16>(t0 + t1, s_wave, n_entries), s1 = s0 + t0;
+    const bool ok0 = s0 <= entries_cap && t0 <= entries_cap - s0, ok1 = s1 <= entries_cap && t1 <= entries_cap - s1;
+    uint32_t r0 = s0, r1 = s1;
+#pragma unroll
+    for (int y = 0; y < 16; y++) {
+        if (b0 < nbins) boff[size_t(y) * nbins + b0] = r0;
+        if (b1 < nbins) boff[size_t(y) * nbins + b1] = r1;
+        r0 += x0[y]; r1 += x1[y];
+    }
+    if (b0 < nbins) { st.start[b0] = s0; st.total[b0] = t0; if (!ok0 && t0) st.overflow = 1u; }
+    if (b1 < nbins) { st.start[b1] = s1; st.total[b1] = t1; if (!ok1 && t1) st.overflow = 1u; }
+    if (tid == 0) st.n_entries = n_entries;
 }
 
 __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const BinRec *__restrict__ records,
                                                         const uint4 *__restrict__ surv,
                                                         const uint32_t *__restrict__ surv_count,
-                                                        const uint32_t *__restrict__ dircount, BinState *__restrict__ state,
+                                                        const uint32_t *__restrict__ dircount,
+                                                        const uint32_t *__restrict__ boff, const BinState *__restrict__ state,
                                                         unsigned long long *__restrict__ entries, uint32_t entries_cap,
                                                         uint64_t *__restrict__ vis) {
-    __shared__ uint32_t start[kMaxBins], base[kMaxBins], cnt[kMaxBins];
+    __shared__ uint32_t base[kMaxBins], cnt[kMaxBins];
     __shared__ uint8_t fits[kMaxBins];
-    __shared__ uint32_t s_wave[kSetupThreads / 64];
     const uint32_t tid = threadIdx.x;
     const int nbins = fp.nbx * fp.nby;
-    BinState &st = state[fp.frame & 1u];
-    // each lane owns bins 2*tid and 2*tid + 1: this workgroup's offset inside them comes from the
-    // scanned count table, the start of each bin's array from an exclusive scan of the totals
-    const int b0 = 2 * int(tid), b1 = b0 + 1;
-    const uint32_t base0 = b0 < nbins ? dircount[size_t(blockIdx.x) * nbins + b0] : 0u;
-    const uint32_t base1 = b1 < nbins ? dircount[size_t(blockIdx.x) * nbins + b1] : 0u;
-    const uint32_t t0 = b0 < nbins ? st.total[b0] : 0u, t1 = b1 < nbins ? st.total[b1] : 0u;
+    const BinState &st = state[fp.frame & 1u];
+    const uint32_t rows_per_block = (fp.n_groups + 15u) / 16u;
+    const uint32_t my_block = blockIdx.x / rows_per_block;
     const uint32_t n = surv_count[blockIdx.x];
-    uint32_t n_entries;
-    const uint32_t s0 = block_exclusive_scan<kSetupThreads / 64>(t0 + t1, s_wave, n_entries), s1 = s0 + t0;
-    const bool ok0 = s0 <= entries_cap && t0 <= entries_cap - s0, ok1 = s1 <= entries_cap && t1 <= entries_cap - s1;
-    if (b0 < nbins) { start[b0] = s0; base[b0] = base0; cnt[b0] = 0; fits[b0] = ok0 ? 1 : 0; }
-    if (b1 < nbins) { start[b1] = s1; base[b1] = base1; cnt[b1] = 0; fits[b1] = ok1 ? 1 : 0; }
-    if (blockIdx.x == 0) {
-        if (b0 < nbins) { st.start[b0] = s0; if (!ok0 && t0) st.overflow = 1u; }
-        if (b1 < nbins) { st.start[b1] = s1; if (!ok1 && t1) st.overflow = 1u; }
-        if (tid == 0) st.n_entries = n_entries;
+    // where this workgroup's entries go inside each bin: start of the bin + entries of earlier row
+    // blocks (boff) + entries of earlier workgroups of its own row block (scanned table)
+    for (int b = int(tid); b < nbins; b += kSetupThreads) {
+        const uint32_t s0 = st.start[b], t0 = st.total[b];
+        base[b] = boff[size_t(my_block) * nbins + b] + dircount[size_t(blockIdx.x) * nbins + b];
+        cnt[b] = 0;
+        fits[b] = (s0 <= entries_cap && t0 <= entries_cap - s0) ? 1 : 0;
     }
     __syncthreads();
     const uint32_t loc_base = blockIdx.x * 2u * fp.chunk;
@@ -787,7 +785,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Bi
                 const uint32_t rowbits = ((1u << (ax1 + 1)) - 1u) & ~((1u << ax0) - 1u);
                 uint32_t m = 0;
                 for (int ay = ay0; ay <= ay1; ay++) m |= rowbits << (kBinSide * ay);
-                entries[size_t(start[b]) + base[b] + atomicAdd(&cnt[b], 1u)] = (unsigned long long)loc | ((unsigned long long)m << 32);
+                entries[size_t(base[b]) + atomicAdd(&cnt[b], 1u)] = (unsigned long long)loc | ((unsigned long long)m << 32);
             }
         if (direct) {  // a bin it touches has no room: resolve through the global key buffer
             Edges e;
@@ -1227,9 +1225,9 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
     const bool tiled = ctx->path == 0 && nt <= size_t(kMaxTiles) && nbins <= size_t(kMaxBins) && cols <= 65535 &&
                        rows <= 65535 && ctx->d_tripos;
     if (tiled) {
-        // k_setup workgroups take chunks of 1024..4096 consecutive triangles (1..kSetupPerLane per lane)
-        uint32_t chunk = (fp.n_tris / 512u + 1023u) / 1024u * 1024u;
-        chunk = chunk < 1024u ? 1024u : (chunk > 4096u ? 4096u : chunk);
+        // one triangle per k_setup lane and pass; more passes only beyond kMaxGroups workgroups
+        uint32_t chunk = (fp.n_tris + kMaxGroups - 1) / kMaxGroups;
+        chunk = (chunk + kSetupThreads - 1) / kSetupThreads * kSetupThreads;
         fp.chunk = chunk;
         fp.n_groups = (fp.n_tris + chunk - 1) / chunk;
         fp.frame = ctx->frame;
@@ -1247,7 +1245,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
             (void)hipFree(ctx->d_surv); (void)hipFree(ctx->d_surv_count);
             ctx->d_surv = nullptr; ctx->d_surv_count = nullptr; ctx->group_cap = 0;
             AR_HIP(ctx, hipMalloc(&ctx->d_surv, want_groups * sizeof(uint4)));
-            AR_HIP(ctx, hipMalloc(&ctx->d_surv_count, (want_groups / 2048 + 1) * sizeof(uint32_t)));
+            AR_HIP(ctx, hipMalloc(&ctx->d_surv_count, (size_t(kMaxGroups) + 1) * sizeof(uint32_t)));
             ctx->group_cap = want_groups;
         }
         const size_t want_dir = size_t(fp.n_groups) * nbins;
@@ -1255,7 +1253,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
             AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
             (void)hipFree(ctx->d_dircount);
             ctx->d_dircount = nullptr; ctx->dircount_cap = 0;
-            AR_HIP(ctx, hipMalloc(&ctx->d_dircount, want_dir * sizeof(uint32_t)));
+            AR_HIP(ctx, hipMalloc(&ctx->d_dircount, (want_dir + 32 * size_t(kMaxBins)) * sizeof(uint32_t)));
             ctx->dircount_cap = want_dir;
         }
     }
@@ -1278,11 +1276,16 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
         }
         {
             Stamper s(ctx, K_BINSCAN);
-            k_binscan<<<unsigned((nbins + 63) / 64), 1024, 0, ctx->stream>>>(fp, ctx->d_dircount, ctx->d_state);
+            k_binscan<<<dim3(unsigned((nbins + 63) / 64), 16), 1024, 0, ctx->stream>>>(fp, ctx->d_dircount, ctx->d_dircount + ctx->dircount_cap);
+        }
+        uint32_t *blocksum = ctx->d_dircount + ctx->dircount_cap, *boff = blocksum + 16 * size_t(kMaxBins);
+        {
+            Stamper s(ctx, K_BINOFF);
+            k_binoffsets<<<1, 1024, 0, ctx->stream>>>(fp, blocksum, boff, ctx->d_state, ctx->pool_cap);
         }
         {
             Stamper s(ctx, K_FILL);
-            k_fill<<<fp.n_groups, kSetupThreads, 0, ctx->stream>>>(fp, ctx->d_records, ctx->d_surv, ctx->d_surv_count, ctx->d_dircount,
+            k_fill<<<fp.n_groups, kSetupThreads, 0, ctx->stream>>>(fp, ctx->d_records, ctx->d_surv, ctx->d_surv_count, ctx->d_dircount, boff,
                                                                   ctx->d_state, ctx->d_entries, ctx->pool_cap, ctx->d_vis);
         }
         {

@@ -97,7 +97,7 @@ int ar_quantize(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *a
 /* Per-kernel timing with HIP events on the context's stream.  While on, every launch is bracketed by
  * events; ar_kernel_stats drains them (blocking) and reports, per kernel slot, the number of launches
  * and the summed duration in milliseconds since the last call.  names receives static strings. */
-#define AR_N_KERNELS 10
+#define AR_N_KERNELS 11
 int ar_set_profiling(ar_ctx *ctx, int on);
 int ar_kernel_stats(ar_ctx *ctx, const char *names[AR_N_KERNELS], uint32_t launches[AR_N_KERNELS], float total_ms[AR_N_KERNELS]);
 
