@@ -841,6 +841,51 @@ __device__ __forceinline__ void shade_from_record(const FrameParams &fp, const f
     shade(fp, v, px);
 }
 
+// Scans rows [r0, r1] x columns [i0, i1] (at most 64 columns) of one record into the LDS key tile.
+// Most cells of a cell range lie outside the triangle, and lanes of a wavefront walk ranges of very
+// different sizes, so the scan is split in two: (1) a cheap pass classifies every cell with a binary32
+// evaluation of the three edge functions and a conservative error band and sets a bit for each cell
+// that is not certainly outside; (2) only those cells pay for the binary64 evaluation that decides
+// coverage and feeds the depth.  The result is exactly that of testing every cell in binary64, but a
+// wavefront executes the expensive path a few times instead of once per cell of its largest range.
+// |e32 - E| <= 2^-22 (|a px| + |r|) for e32 = fl(fl(a32 px) + r32); the band used is 16 times wider.
+__device__ __forceinline__ void raster_range(const FrameParams &fp, const Edges &ed, uint32_t key_low, int i0, int i1,
+                                             int r0, int r1, int tx0, int tr0, uint64_t *keys) {
+    constexpr float kBand = 1.0f / 262144.0f;  // 2^-18
+    const float a32[3] = {float(ed.a[0]), float(ed.a[1]), float(ed.a[2])};
+    const float px_max = float(i1 + 1);
+    const int w = i1 - i0 + 1;
+    const int rows_per_chunk = max(1, 64 / w);
+    const float inv_w = 1.0f / float(w);
+    for (int rc = r0; rc <= r1; rc += rows_per_chunk) {
+        const int rc1 = min(rc + rows_per_chunk - 1, r1);
+        unsigned long long cand = 0ull;
+        for (int rr = rc; rr <= rc1; rr++) {
+            const double py = double(fp.rows - 1 - rr) + 0.5;
+            const float r32[3] = {float(ed.b[0] * py + ed.c[0]), float(ed.b[1] * py + ed.c[1]), float(ed.b[2] * py + ed.c[2])};
+            const float band[3] = {kBand * (fabsf(a32[0]) * px_max + fabsf(r32[0])), kBand * (fabsf(a32[1]) * px_max + fabsf(r32[1])),
+                                   kBand * (fabsf(a32[2]) * px_max + fabsf(r32[2]))};
+            unsigned long long bit = 1ull << ((rr - rc) * w);
+            for (int i = i0; i <= i1; i++, bit <<= 1) {
+                const float px32 = float(i) + 0.5f;
+                const bool out = a32[0] * px32 + r32[0] < -band[0] || a32[1] * px32 + r32[1] < -band[1] ||
+                                 a32[2] * px32 + r32[2] < -band[2];
+                if (!out) cand |= bit;
+            }
+        }
+        while (cand) {
+            const int k = __ffsll((long long)cand) - 1;
+            cand &= cand - 1ull;
+            const int dr = int((float(k) + 0.5f) * inv_w);  // k / w, exact for k < 64
+            const int rr = rc + dr, i = i0 + (k - dr * w);
+            float f[3], zw;
+            if (cover(ed, i, fp.rows - 1 - rr, f, zw))
+                atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
+                          (unsigned long long)make_key(zw, key_low));
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__restrict__ vbo,
                                               const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
                                               const float *__restrict__ tripos, size_t stride,
@@ -895,15 +940,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
                 }
                 Edges ed;
                 edges_from_screen(rec, ed);
-                for (int rr = r0; rr <= r1; rr++) {
-                    const int j = fp.rows - 1 - rr;
-                    for (int i = i0; i <= i1; i++) {
-                        float f[3], zw;
-                        if (cover(ed, i, j, f, zw))
-                            atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
-                                      (unsigned long long)make_key(zw, loc));
-                    }
-                }
+                raster_range(fp, ed, loc, i0, i1, r0, r1, tx0, tr0, keys);
             }
             __syncthreads();
             // sweep list: all lanes cover one record's cell range, 256 cells per step
