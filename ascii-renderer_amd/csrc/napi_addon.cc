@@ -1,0 +1,268 @@
+// napi_addon.cc - thin N-API binding of the C ABI in include/ascii_rast.h for the JavaScript host.
+//
+// Every export is a one-to-one wrapper: typed arrays in, status out.  Setup calls throw a JS Error
+// carrying ar_last_error(); nothing here computes anything.  The handle returned by create() is an
+// external whose finalizer destroys the context if the host forgot to.
+#include <node_api.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "ascii_rast.h"
+
+namespace {
+
+#define NAPI_OK(env, call)                                                       \
+    do {                                                                         \
+        if ((call) != napi_ok) {                                                 \
+            napi_throw_error(env, nullptr, "ascii_rast addon: N-API call failed: " #call); \
+            return nullptr;                                                      \
+        }                                                                        \
+    } while (0)
+
+struct Handle {
+    ar_ctx *ctx;
+};
+
+void finalize_handle(napi_env, void *data, void *) {
+    Handle *h = static_cast<Handle *>(data);
+    if (h->ctx) ar_destroy(h->ctx);
+    delete h;
+}
+
+napi_value throw_ar(napi_env env, ar_ctx *ctx, const char *what) {
+    char msg[384];
+    snprintf(msg, sizeof msg, "%s: %s", what, ar_last_error(ctx));
+    napi_throw_error(env, nullptr, msg);
+    return nullptr;
+}
+
+bool get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv) {
+    size_t argc = want;
+    if (napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr) != napi_ok || argc < want) {
+        napi_throw_type_error(env, nullptr, "ascii_rast addon: missing arguments");
+        return false;
+    }
+    return true;
+}
+
+ar_ctx *get_ctx(napi_env env, napi_value v) {
+    void *p = nullptr;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !static_cast<Handle *>(p)->ctx) {
+        napi_throw_type_error(env, nullptr, "ascii_rast addon: invalid or destroyed renderer handle");
+        return nullptr;
+    }
+    return static_cast<Handle *>(p)->ctx;
+}
+
+// Typed array (or null/undefined -> nullptr, length 0).  want: napi_float32_array, napi_uint32_array,
+// napi_uint8_array (Uint8ClampedArray is accepted where Uint8Array is).
+bool get_typed(napi_env env, napi_value v, napi_typedarray_type want, void **data, size_t *length, bool allow_null) {
+    napi_valuetype vt;
+    napi_typeof(env, v, &vt);
+    if (vt == napi_null || vt == napi_undefined) {
+        *data = nullptr; *length = 0;
+        if (!allow_null) napi_throw_type_error(env, nullptr, "ascii_rast addon: typed array expected");
+        return allow_null;
+    }
+    bool is_ta = false;
+    napi_is_typedarray(env, v, &is_ta);
+    if (!is_ta) { napi_throw_type_error(env, nullptr, "ascii_rast addon: typed array expected"); return false; }
+    napi_typedarray_type type;
+    napi_value buf;
+    size_t off;
+    if (napi_get_typedarray_info(env, v, &type, length, data, &buf, &off) != napi_ok) return false;
+    const bool ok = type == want || (want == napi_uint8_array && type == napi_uint8_clamped_array);
+    if (!ok) napi_throw_type_error(env, nullptr, "ascii_rast addon: typed array of the wrong element type");
+    return ok;
+}
+
+int32_t get_i32(napi_env env, napi_value v) {
+    int32_t x = 0;
+    napi_get_value_int32(env, v, &x);
+    return x;
+}
+
+napi_value js_create(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    ar_ctx *ctx = ar_create(get_i32(env, argv[0]));
+    if (!ctx) return throw_ar(env, nullptr, "ar_create");
+    Handle *h = new Handle{ctx};
+    napi_value ext;
+    NAPI_OK(env, napi_create_external(env, h, finalize_handle, nullptr, &ext));
+    return ext;
+}
+
+napi_value js_destroy(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    void *p = nullptr;
+    if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
+        Handle *h = static_cast<Handle *>(p);
+        if (h->ctx) { ar_destroy(h->ctx); h->ctx = nullptr; }  // idempotent, like RasterBackend.dispose
+    }
+    return nullptr;
+}
+
+napi_value js_set_mesh(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    void *vbo, *idx;
+    size_t nv, ni;
+    if (!get_typed(env, argv[1], napi_float32_array, &vbo, &nv, true)) return nullptr;
+    if (!get_typed(env, argv[2], napi_uint32_array, &idx, &ni, true)) return nullptr;
+    if (nv % 9 || ni % 3) { napi_throw_range_error(env, nullptr, "setMesh: vbo needs 9 floats per vertex, idx 3 per triangle"); return nullptr; }
+    if (ar_set_mesh(ctx, static_cast<const float *>(vbo), uint32_t(nv / 9), static_cast<const uint32_t *>(idx), uint32_t(ni / 3)))
+        return throw_ar(env, ctx, "ar_set_mesh");
+    return nullptr;
+}
+
+napi_value js_set_camera(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    void *p, *v;
+    size_t np, nv;
+    if (!get_typed(env, argv[1], napi_float32_array, &p, &np, false) || !get_typed(env, argv[2], napi_float32_array, &v, &nv, false)) return nullptr;
+    if (np != 16 || nv != 16) { napi_throw_range_error(env, nullptr, "setCamera: two Float32Array(16) expected"); return nullptr; }
+    if (ar_set_camera(ctx, static_cast<const float *>(p), static_cast<const float *>(v))) return throw_ar(env, ctx, "ar_set_camera");
+    return nullptr;
+}
+
+napi_value js_set_lights(napi_env env, napi_callback_info info) {
+    napi_value argv[6];
+    if (!get_args(env, info, 6, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    void *a, *d, *c, *pp, *pc;
+    size_t na, nd, nc, npp, npc;
+    if (!get_typed(env, argv[1], napi_float32_array, &a, &na, false) || !get_typed(env, argv[2], napi_float32_array, &d, &nd, false) ||
+        !get_typed(env, argv[3], napi_float32_array, &c, &nc, false) || !get_typed(env, argv[4], napi_float32_array, &pp, &npp, true) ||
+        !get_typed(env, argv[5], napi_float32_array, &pc, &npc, true))
+        return nullptr;
+    if (na < 3 || nd < 3 || nc < 3 || npp != npc || npp % 3) { napi_throw_range_error(env, nullptr, "setLights: bad array sizes"); return nullptr; }
+    if (ar_set_lights(ctx, static_cast<const float *>(a), static_cast<const float *>(d), static_cast<const float *>(c), int(npp / 3),
+                      static_cast<const float *>(pp), static_cast<const float *>(pc)))
+        return throw_ar(env, ctx, "ar_set_lights");
+    return nullptr;
+}
+
+napi_value js_set_ascii(napi_env env, napi_callback_info info) {
+    napi_value argv[5];
+    if (!get_args(env, info, 5, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    void *ramp;
+    size_t n;
+    if (!get_typed(env, argv[1], napi_uint8_array, &ramp, &n, false)) return nullptr;
+    bool on = false;
+    napi_get_value_bool(env, argv[2], &on);
+    if (ar_set_ascii(ctx, static_cast<const uint8_t *>(ramp), int(n), on ? 1 : 0, get_i32(env, argv[3]), get_i32(env, argv[4])))
+        return throw_ar(env, ctx, "ar_set_ascii");
+    return nullptr;
+}
+
+napi_value js_set_strip(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    if (ar_set_strip(ctx, get_i32(env, argv[1]), get_i32(env, argv[2]))) return throw_ar(env, ctx, "ar_set_strip");
+    return nullptr;
+}
+
+napi_value js_set_option(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    int64_t v = 0;
+    napi_get_value_int64(env, argv[2], &v);
+    if (ar_set_option(ctx, get_i32(env, argv[1]), v)) return throw_ar(env, ctx, "ar_set_option");
+    return nullptr;
+}
+
+// render(handle, cols, rows, rgba|null, depth|null, ascii|null) -> true when a frame was drawn,
+// false when there is no geometry (buffers untouched), throws on size mismatch or device errors.
+napi_value js_render(napi_env env, napi_callback_info info) {
+    napi_value argv[6];
+    if (!get_args(env, info, 6, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    const int cols = get_i32(env, argv[1]), rows = get_i32(env, argv[2]);
+    void *rgba, *depth, *ascii;
+    size_t nr, nd, na;
+    if (!get_typed(env, argv[3], napi_uint8_array, &rgba, &nr, true) || !get_typed(env, argv[4], napi_float32_array, &depth, &nd, true) ||
+        !get_typed(env, argv[5], napi_uint8_array, &ascii, &na, true))
+        return nullptr;
+    const size_t n = size_t(cols > 0 ? cols : 0) * size_t(rows > 0 ? rows : 0);
+    if ((rgba && nr != n * 4) || (depth && nd != n) || (ascii && na != n)) {
+        napi_throw_range_error(env, nullptr, "render: output array size does not match cols*rows");
+        return nullptr;
+    }
+    if (ar_render(ctx, cols, rows, static_cast<uint8_t *>(rgba), static_cast<float *>(depth), static_cast<uint8_t *>(ascii)))
+        return throw_ar(env, ctx, "ar_render");
+    uint32_t c[8];
+    napi_value out;
+    napi_get_boolean(env, ar_frame_counters(ctx, c) == 0 && c[0] > 0, &out);
+    return out;
+}
+
+napi_value js_quantize(napi_env env, napi_callback_info info) {
+    napi_value argv[5];
+    if (!get_args(env, info, 5, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    void *rgba, *ascii;
+    size_t nr, na;
+    const int cols = get_i32(env, argv[2]), rows = get_i32(env, argv[3]);
+    if (!get_typed(env, argv[1], napi_uint8_array, &rgba, &nr, false) || !get_typed(env, argv[4], napi_uint8_array, &ascii, &na, false)) return nullptr;
+    const size_t n = size_t(cols > 0 ? cols : 0) * size_t(rows > 0 ? rows : 0);
+    if (nr != n * 4 || na != n) { napi_throw_range_error(env, nullptr, "quantize: array sizes do not match cols*rows"); return nullptr; }
+    if (ar_quantize(ctx, static_cast<const uint8_t *>(rgba), cols, rows, static_cast<uint8_t *>(ascii))) return throw_ar(env, ctx, "ar_quantize");
+    return nullptr;
+}
+
+napi_value js_frame_counters(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    uint32_t c[8];
+    if (ar_frame_counters(ctx, c)) return throw_ar(env, ctx, "ar_frame_counters");
+    napi_value arr;
+    NAPI_OK(env, napi_create_array_with_length(env, 8, &arr));
+    for (uint32_t k = 0; k < 8; k++) {
+        napi_value v;
+        napi_create_uint32(env, c[k], &v);
+        napi_set_element(env, arr, k, v);
+    }
+    return arr;
+}
+
+napi_value init(napi_env env, napi_value exports) {
+    const napi_property_descriptor props[] = {
+        {"create", nullptr, js_create, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"destroy", nullptr, js_destroy, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setMesh", nullptr, js_set_mesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setCamera", nullptr, js_set_camera, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setLights", nullptr, js_set_lights, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setAscii", nullptr, js_set_ascii, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setStrip", nullptr, js_set_strip, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setOption", nullptr, js_set_option, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"render", nullptr, js_render, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"quantize", nullptr, js_quantize, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"frameCounters", nullptr, js_frame_counters, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+    };
+    napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
+    return exports;
+}
+
+}  // namespace
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

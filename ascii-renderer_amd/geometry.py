@@ -6,6 +6,8 @@ the interchange shape SceneBuilder.addMesh accepts (js/render/scene_api.js:169-1
 Both language twins draw from the same mulberry32 stream in the same order and use the same
 literal constants, so they produce bit-identical binary32 meshes.
 """
+import math
+
 import numpy as np
 
 TAN40 = 0.8390996311772799       # tan(40 deg): half of the reference's fixed 80 deg vertical fov
@@ -41,10 +43,11 @@ def cube(half=0.5):
 
 def icosphere(subdiv=4, radius=1.0):
     """Unit icosahedron subdivided `subdiv` times (20 * 4**subdiv triangles), outward CCW."""
-    t = (1.0 + 5.0 ** 0.5) / 2.0
+    t = (1.0 + math.sqrt(5.0)) / 2.0
     verts = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t),
              (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
-    verts = [tuple(np.asarray(v, dtype=np.float64) / np.sqrt(1.0 + t * t)) for v in verts]
+    s = math.sqrt(1.0 + t * t)
+    verts = [(v[0] / s, v[1] / s, v[2] / s) for v in verts]
     faces = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4),
              (11, 10, 2), (10, 7, 6), (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8),
              (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
@@ -56,7 +59,7 @@ def icosphere(subdiv=4, radius=1.0):
             if key not in cache:
                 a, b = verts[key[0]], verts[key[1]]
                 m = ((a[0] + b[0]) * 0.5, (a[1] + b[1]) * 0.5, (a[2] + b[2]) * 0.5)
-                L = (m[0] * m[0] + m[1] * m[1] + m[2] * m[2]) ** 0.5
+                L = math.sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2])
                 verts.append((m[0] / L, m[1] / L, m[2] / L))
                 cache[key] = len(verts) - 1
             return cache[key]

@@ -1,0 +1,309 @@
+// hip_backend.js - the raster backend behind the router: host half in JavaScript, device half in the
+// HIP library (through the N-API addon).
+//
+// Contract (reference js/render/backends/raster.js:51-71,116-133,269-272,364-375):
+//   name; setScene(scene|null); render(timeSec, framebuffer, appState) -> undefined;
+//   renderRaw({time, framebuffer, appState}); getPixels({framebuffer, width, height, flipY=true});
+//   dispose() (idempotent).
+// The caller owns `framebuffer` (Uint8Array / Uint8ClampedArray of cols*rows*4, row 0 = top); it is
+// filled synchronously, and silently left alone when its length does not match (raster.js:360).
+// Geometry is snapshotted at setScene; the camera is read live from camera.js at render time and the
+// grid size from appState.cols / rows (raster.js:271-272, 284-286).
+// Beyond the reference: appState.depth (Float32Array cols*rows) and appState.ascii (Uint8Array
+// cols*rows) are filled when present, and a scene may carry `mesh` = {positions: Float32Array,
+// indices: Uint32Array, colors?: Float32Array (per triangle)} as a typed-array fast path.
+import { config } from './config.js';
+import { camera as LiveCamera } from './camera.js';
+import { native, AR_OPT_PATH } from './native.js';
+
+export const MAX_POINT_LIGHTS = 8;                       // raster_shader.js:5
+const DEFAULT_AMBIENT = [0.15, 0.18, 0.22];              // raster.js:66
+const DEFAULT_LIGHT_DIR = [0.25, -1.0, 0.15];            // raster.js:67 (not normalized; kept)
+const DEFAULT_LIGHT_COLOR = [1.2, 1.15, 1.1];            // raster.js:68
+const LEGACY_COLORS = { 0: [5, 5, 5], 1: [0.9, 0.9, 0.9], 2: [0.7, 0.9, 0.7], 3: [0.95, 0.45, 0.45], 6: [0.9, 0.95, 1.0] };
+const FALLBACK_COLOR = [0.8, 0.8, 0.8];
+const SPHERE_LAT = 12, SPHERE_LON = 16;                  // raster.js:197
+const PLANE_HALF_SIZE = 20.0;                            // raster.js:187
+
+/* ------------------------------- small math -------------------------------- */
+function cross(a, b) { return [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]; }
+function dot(a, b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+function normalize(v) { const L = Math.hypot(v[0], v[1], v[2]) || 1; return [v[0] / L, v[1] / L, v[2] / L]; }
+const clamp01 = (v) => Math.min(1, Math.max(0, v));
+
+// raster.js:15-22, column-major
+export function mat4Perspective(fovyRad, aspect, near, far) {
+  const f = 1 / Math.tan(Math.max(1e-6, fovyRad * 0.5)), nf = 1 / (near - far);
+  const out = new Float32Array(16);
+  out[0] = f / aspect; out[5] = f; out[10] = (far + near) * nf; out[11] = -1; out[14] = 2 * far * near * nf;
+  return out;
+}
+
+// raster.js:41-45: yaw = pitch = 0 looks along +X
+export function yawPitchToDir(yaw, pitch) {
+  const cp = Math.cos(pitch), sp = Math.sin(pitch), cy = Math.cos(yaw), sy = Math.sin(yaw);
+  return [cp * cy, sp, cp * sy];
+}
+
+// raster.js:30-39, column-major
+export function mat4LookAt(eye, center, up) {
+  const f = normalize([center[0] - eye[0], center[1] - eye[1], center[2] - eye[2]]);
+  const s = normalize(cross(f, up));
+  const u = cross(s, f);
+  const out = new Float32Array(16);
+  out[0] = s[0]; out[1] = u[0]; out[2] = -f[0];
+  out[4] = s[1]; out[5] = u[1]; out[6] = -f[1];
+  out[8] = s[2]; out[9] = u[2]; out[10] = -f[2];
+  out[12] = -dot(s, eye); out[13] = -dot(u, eye); out[14] = dot(f, eye); out[15] = 1;
+  return out;
+}
+
+// Projection and view exactly as RasterBackend.render uploads them (raster.js:284-304).  The
+// reference reads config.FOVY_DEG, which does not exist, so the field of view is always 80 degrees.
+export function cameraMatrices(cam, cols, rows) {
+  const eye = [cam.pos.x, cam.pos.y, cam.pos.z];
+  const dir = yawPitchToDir(cam.yaw || 0, cam.pitch || 0);
+  const center = [eye[0] + dir[0], eye[1] + dir[1], eye[2] + dir[2]];
+  const pixAsp = (config.PATH_TRACER && Number.isFinite(config.PATH_TRACER.PIXEL_ASPECT))
+    ? Math.max(1e-6, config.PATH_TRACER.PIXEL_ASPECT) : 1.0;
+  const fovRad = ((config.FOVY_DEG || 80) * Math.PI / 180);
+  const aspect = Math.max(1e-6, (cols / Math.max(1, rows)) * pixAsp);
+  return { proj: mat4Perspective(fovRad, aspect, 0.05, 100.0), view: mat4LookAt(eye, center, [0, 1, 0]) };
+}
+
+// Light uniforms as raster.js:307-342 packs them.
+export function packLights(scene) {
+  const U = scene || {}, L = U.lights || null;
+  let ambient = DEFAULT_AMBIENT, dirDir = DEFAULT_LIGHT_DIR, dirCol = DEFAULT_LIGHT_COLOR;
+  if (L && L.env) {
+    const e = L.env, k = e.intensity || 0, c = e.color || [];
+    ambient = [(c[0] || 0) * k, (c[1] || 0) * k, (c[2] || 0) * k];
+  } else if (U.envLight && U.envLight.color) {
+    ambient = U.envLight.color;
+  }
+  if (L && L.directionals && L.directionals.length) {
+    const d0 = L.directionals[0], k = d0.intensity || 0, c = d0.color || [];
+    dirDir = d0.dir || dirDir;
+    dirCol = [(c[0] || 1) * k, (c[1] || 1) * k, (c[2] || 1) * k];
+  } else if (U.dirLight && U.dirLight.dir) {
+    dirDir = U.dirLight.dir;
+    dirCol = U.dirLight.color || dirCol;
+  }
+  const pts = (L && L.points && L.points.length) ? L.points : [];
+  const n = Math.min(MAX_POINT_LIGHTS, pts.length);
+  const plPos = new Float32Array(n * 3), plCol = new Float32Array(n * 3);
+  for (let i = 0; i < n; i++) {
+    const p = pts[i].p || [0, 0, 0], c = pts[i].color || [1, 1, 1], k = +pts[i].intensity || 0;
+    plPos[i * 3] = p[0]; plPos[i * 3 + 1] = p[1]; plPos[i * 3 + 2] = p[2];
+    plCol[i * 3] = c[0] * k; plCol[i * 3 + 1] = c[1] * k; plCol[i * 3 + 2] = c[2] * k;
+  }
+  return {
+    ambient: new Float32Array([ambient[0], ambient[1], ambient[2]]),
+    dir: new Float32Array([dirDir[0], dirDir[1], dirDir[2]]),
+    dirColor: new Float32Array([dirCol[0], dirCol[1], dirCol[2]]),
+    plPos, plCol,
+  };
+}
+
+// raster.js:135-146
+export function resolveColor(scene, mat, m) {
+  if (scene && Array.isArray(scene.materials) && Number.isFinite(mat)) {
+    const M = scene.materials[mat | 0];
+    if (M && M.albedo) return [clamp01(+M.albedo[0] || 0), clamp01(+M.albedo[1] || 0), clamp01(+M.albedo[2] || 0)];
+  }
+  if (Number.isFinite(m)) return LEGACY_COLORS[m | 0] || FALLBACK_COLOR;
+  return FALLBACK_COLOR;
+}
+
+// Scene object -> { vbo: Float32Array(9 * V) (pos, normal, colour), idx: Uint32Array(3 * T) }, the
+// buffers RasterBackend._rebuildGeometry uploads (raster.js:148-257): tris (flat normal), planes
+// (two triangles of half-size 20), spheres (12 x 16 UV mesh); quads are ignored as in the reference.
+export function buildGeometry(scene) {
+  if (!scene) return { vbo: new Float32Array(0), idx: new Uint32Array(0) };
+  if (scene.mesh && scene.mesh.positions && scene.mesh.indices) return meshToVbo(scene.mesh.positions, scene.mesh.indices, scene.mesh.colors);
+  const pos = [], nrm = [], col = [], idx = [];
+  const pushTri = (a, b, c, color) => {
+    const U = [b[0] - a[0], b[1] - a[1], b[2] - a[2]], V = [c[0] - a[0], c[1] - a[1], c[2] - a[2]];
+    let N = cross(U, V);
+    const L = Math.hypot(N[0], N[1], N[2]);
+    N = L > 1e-8 ? [N[0] / L, N[1] / L, N[2] / L] : [0, 1, 0];
+    const base = pos.length / 3;
+    pos.push(a[0], a[1], a[2], b[0], b[1], b[2], c[0], c[1], c[2]);
+    nrm.push(N[0], N[1], N[2], N[0], N[1], N[2], N[0], N[1], N[2]);
+    col.push(color[0], color[1], color[2], color[0], color[1], color[2], color[0], color[1], color[2]);
+    idx.push(base, base + 1, base + 2);
+  };
+  const G = scene.geometry || {};
+  for (const t of (scene.tris || G.tris || [])) {
+    pushTri(t.a || [0, 0, 0], t.b || [1, 0, 0], t.c || [0, 1, 0], resolveColor(scene, t.mat, t.m));
+  }
+  for (const p of (scene.planes || G.planes || [])) {
+    const n = p.n || [0, 1, 0], d = Number.isFinite(p.d) ? p.d : 0, color = resolveColor(scene, p.mat, p.m);
+    const N = normalize([n[0], n[1], n[2]]);
+    const P0 = [-d * N[0], -d * N[1], -d * N[2]];
+    const tmp = Math.abs(N[1]) < 0.99 ? [0, 1, 0] : [1, 0, 0];
+    const b1 = normalize(cross(N, tmp)), b2 = normalize(cross(N, b1)), S = PLANE_HALF_SIZE;
+    const corner = (s1, s2) => [P0[0] + (s1 * S * b1[0] + s2 * S * b2[0]), P0[1] + (s1 * S * b1[1] + s2 * S * b2[1]), P0[2] + (s1 * S * b1[2] + s2 * S * b2[2])];
+    const v0 = corner(-1, -1), v1 = corner(1, -1), v2 = corner(1, 1), v3 = corner(-1, 1);
+    pushTri(v0, v1, v2, color); pushTri(v0, v2, v3, color);
+  }
+  for (const s of (scene.spheres || G.spheres || [])) {
+    const c = s.p || [0, 0, 0], r = Number.isFinite(s.r) ? s.r : 1, color = resolveColor(scene, s.mat, s.m);
+    const baseVert = pos.length / 3;
+    for (let iy = 0; iy <= SPHERE_LAT; iy++) {
+      const phi = (iy / SPHERE_LAT) * Math.PI, sp = Math.sin(phi), cp = Math.cos(phi);
+      for (let ix = 0; ix <= SPHERE_LON; ix++) {
+        const th = (ix / SPHERE_LON) * 2 * Math.PI, st = Math.sin(th), ct = Math.cos(th);
+        const nx = ct * sp, ny = cp, nz = st * sp;
+        pos.push(c[0] + r * nx, c[1] + r * ny, c[2] + r * nz);
+        nrm.push(nx, ny, nz);
+        col.push(color[0], color[1], color[2]);
+      }
+    }
+    for (let iy = 0; iy < SPHERE_LAT; iy++) {
+      for (let ix = 0; ix < SPHERE_LON; ix++) {
+        const i0 = baseVert + iy * (SPHERE_LON + 1) + ix, i1 = i0 + 1, i2 = i0 + (SPHERE_LON + 1), i3 = i2 + 1;
+        idx.push(i0, i2, i1, i1, i2, i3);
+      }
+    }
+  }
+  const V = pos.length / 3, vbo = new Float32Array(V * 9);
+  for (let i = 0; i < V; i++) {
+    vbo[i * 9] = pos[i * 3]; vbo[i * 9 + 1] = pos[i * 3 + 1]; vbo[i * 9 + 2] = pos[i * 3 + 2];
+    vbo[i * 9 + 3] = nrm[i * 3]; vbo[i * 9 + 4] = nrm[i * 3 + 1]; vbo[i * 9 + 5] = nrm[i * 3 + 2];
+    vbo[i * 9 + 6] = col[i * 3]; vbo[i * 9 + 7] = col[i * 3 + 1]; vbo[i * 9 + 8] = col[i * 3 + 2];
+  }
+  return { vbo, idx: new Uint32Array(idx) };
+}
+
+// Typed-array fast path: indexed mesh -> the reference's unshared, flat-shaded layout without any
+// per-triangle JS objects.  Normal = normalize(cross(b - a, c - a)) in binary64, (0, 1, 0) when its
+// length is <= 1e-8 (raster.js:159-163); colour = per-triangle albedo or (0.8, 0.8, 0.8).
+export function meshToVbo(positions, indices, colors) {
+  const T = (indices.length / 3) | 0, vbo = new Float32Array(T * 27), idx = new Uint32Array(T * 3);
+  for (let t = 0; t < T; t++) {
+    const ia = indices[3 * t] * 3, ib = indices[3 * t + 1] * 3, ic = indices[3 * t + 2] * 3;
+    const ax = positions[ia], ay = positions[ia + 1], az = positions[ia + 2];
+    const ux = positions[ib] - ax, uy = positions[ib + 1] - ay, uz = positions[ib + 2] - az;
+    const vx = positions[ic] - ax, vy = positions[ic + 1] - ay, vz = positions[ic + 2] - az;
+    let nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+    const L = Math.sqrt(nx * nx + ny * ny + nz * nz);
+    if (L > 1e-8) { nx /= L; ny /= L; nz /= L; } else { nx = 0; ny = 1; nz = 0; }
+    const r = colors ? colors[3 * t] : FALLBACK_COLOR[0], g = colors ? colors[3 * t + 1] : FALLBACK_COLOR[1], b = colors ? colors[3 * t + 2] : FALLBACK_COLOR[2];
+    for (let k = 0; k < 3; k++) {
+      const src = indices[3 * t + k] * 3, o = (3 * t + k) * 9;
+      vbo[o] = positions[src]; vbo[o + 1] = positions[src + 1]; vbo[o + 2] = positions[src + 2];
+      vbo[o + 3] = nx; vbo[o + 4] = ny; vbo[o + 5] = nz;
+      vbo[o + 6] = r; vbo[o + 7] = g; vbo[o + 8] = b;
+      idx[3 * t + k] = 3 * t + k;
+    }
+  }
+  return { vbo, idx };
+}
+
+// context.js:117-124
+export function flipAndCopy(src, dst, w, h) {
+  const row = w * 4;
+  for (let y = 0; y < h; y++) dst.set(src.subarray((h - 1 - y) * row, (h - 1 - y) * row + row), y * row);
+}
+
+export function rampBytes(ramp) {
+  const s = String(ramp), out = new Uint8Array(s.length);
+  for (let i = 0; i < s.length; i++) out[i] = s.charCodeAt(i) & 0xFF;
+  return out;
+}
+
+// Modal-smoothing uniforms from config, as AsciiPass derives them (js/ascii_pass.js:149-152, 294-299).
+export function modeParams() {
+  const k = Math.max(3, (config.ASCII_MODE_KERNEL | 0) || 3);
+  return {
+    on: !!config.ASCII_MODE_FILTER,
+    radius: Math.max(1, Math.min(3, Math.max(1, ((k - 1) / 2) | 0))),
+    thresh: Math.max(1, (config.ASCII_MODE_THRESH | 0) || 5),
+  };
+}
+
+/* -------------------------------- backend ---------------------------------- */
+export class HipRasterBackend {
+  constructor(opts) {
+    this.name = 'hip';
+    this._device = (opts && opts.device) | 0;
+    this._h = null;
+    this._scene = null;
+    this._hasGeometry = false;
+    this._width = 0; this._height = 0;
+    this._lastTopDown = null;   // last frame, row 0 = top
+    this._forceDirect = !!(opts && opts.directPath);
+  }
+
+  _ensure() {
+    if (this._h) return;
+    this._h = native().create(this._device);
+    if (this._forceDirect) native().setOption(this._h, AR_OPT_PATH, 1);
+  }
+
+  dispose() {
+    if (this._h) native().destroy(this._h);
+    this._h = null;
+    this._lastTopDown = null;
+    this._hasGeometry = false;
+  }
+
+  setScene(scene) {
+    this._scene = scene || null;
+    this._ensure();
+    const g = buildGeometry(this._scene);
+    native().setMesh(this._h, g.vbo, g.idx);
+    this._hasGeometry = g.idx.length > 0;
+  }
+
+  render(timeSec, framebuffer, appState) {
+    this._ensure();
+    const w = ((appState && appState.cols) | 0) || (config.VIRTUAL_GRID_WIDTH | 0) || 1;
+    const h = ((appState && appState.rows) | 0) || (config.VIRTUAL_GRID_HEIGHT | 0) || 1;
+    this._width = w; this._height = h;
+    if (!this._hasGeometry) return;                      // raster.js:274
+    const cam = LiveCamera
+      ? { pos: LiveCamera.pos, yaw: LiveCamera.yaw, pitch: LiveCamera.pitch }
+      : ((appState && appState.camera) || { pos: { x: 0, y: 0, z: 5 }, yaw: 0, pitch: 0 });
+    const m = cameraMatrices(cam, w, h);
+    const L = packLights(this._scene);
+    const mode = modeParams();
+    const N = native();
+    N.setCamera(this._h, m.proj, m.view);
+    N.setLights(this._h, L.ambient, L.dir, L.dirColor, L.plPos, L.plCol);
+    N.setAscii(this._h, rampBytes(config.ASCII_RAMP || '@%#*+=-:. '), mode.on, mode.radius, mode.thresh);
+    if (!this._lastTopDown || this._lastTopDown.length !== w * h * 4) this._lastTopDown = new Uint8Array(w * h * 4);
+    const depth = (appState && appState.depth && appState.depth.length === w * h) ? appState.depth : null;
+    const ascii = (appState && appState.ascii && appState.ascii.length === w * h) ? appState.ascii : null;
+    N.render(this._h, w, h, this._lastTopDown, depth, ascii);
+    if (framebuffer && framebuffer.length === this._lastTopDown.length) framebuffer.set(this._lastTopDown);
+  }
+
+  renderRaw(args) {
+    if (args && args.framebuffer && args.appState) return this.render(args.time || 0, args.framebuffer, args.appState);
+    return undefined;
+  }
+
+  // The reference keeps the bottom-up readPixels image and flips on request (raster.js:366-375);
+  // this backend keeps the top-down image, so flipY = true is the plain copy.
+  getPixels(args) {
+    const a = args || {};
+    if (!this._lastTopDown) return null;
+    const w = a.width || this._width, h = a.height || this._height;
+    const flipY = a.flipY === undefined ? true : !!a.flipY;
+    const bottomUp = () => { const out = new Uint8Array(w * h * 4); flipAndCopy(this._lastTopDown, out, w, h); return out; };
+    if (a.framebuffer && a.framebuffer.length >= w * h * 4) {
+      if (flipY) a.framebuffer.set(this._lastTopDown);
+      else flipAndCopy(this._lastTopDown, a.framebuffer, w, h);
+      return a.framebuffer;
+    }
+    return bottomUp();                                   // raw image as read back: bottom-up
+  }
+
+  frameCounters() {
+    this._ensure();
+    const c = native().frameCounters(this._h);
+    return { triangles: c[0], mediumRecords: c[1], largeRecords: c[2], binEntries: c[3], poolOverflow: c[4], tiled: c[5] };
+  }
+}

@@ -1,0 +1,84 @@
+// GPU harness: replays the reference application's call sequence (js/main.js:173-248, 364-375, 421-424)
+// against the HIP backend through the router and writes the frame to disk for the Python side to
+// compare with the oracle.   node tests/js/gpu_frame.mjs <out dir>
+import fs from 'fs';
+import path from 'path';
+import { fileURLToPath } from 'url';
+
+const here = path.dirname(fileURLToPath(import.meta.url));
+const JS = path.join(here, '..', '..', 'ascii-renderer_amd', 'js');
+const outDir = process.argv[2];
+const dump = (name, ta) => fs.writeFileSync(path.join(outDir, name), Buffer.from(ta.buffer, ta.byteOffset, ta.byteLength));
+
+(async () => {
+  const { config } = await import(path.join(JS, 'config.js'));
+  const { setCamera } = await import(path.join(JS, 'camera.js'));
+  const router = await import(path.join(JS, 'gpu_renderer.js'));
+  const geometry = await import(path.join(JS, 'geometry.js'));
+  const sceneApi = await import(path.join(JS, 'scene_api.js'));
+  const { AsciiPass } = await import(path.join(JS, 'ascii_pass.js'));
+  const meta = { frames: [] };
+
+  // init(): backend by name/alias, pixel aspect, scene, camera, buffers
+  if (router.setBackend('raster') !== 'hip') throw new Error('alias raster should resolve to hip');
+  config.PATH_TRACER.PIXEL_ASPECT = 0.5;
+
+  function frame(name, scene, cam, cols, rows) {
+    router.setScene(scene);
+    setCamera(cam.pos, cam.yaw, cam.pitch);
+    const fb = new Uint8ClampedArray(cols * rows * 4);
+    const state = { cols, rows, depth: new Float32Array(cols * rows), ascii: new Uint8Array(cols * rows) };
+    const ret = router.renderScene(0.0, fb, state);
+    if (ret !== undefined) throw new Error('render must return undefined');
+    dump(name + '.rgba', fb); dump(name + '.depth', state.depth); dump(name + '.ascii', state.ascii);
+    meta.frames.push({ name, cols, rows, cam, pixelAspect: config.PATH_TRACER.PIXEL_ASPECT });
+    return { fb, state };
+  }
+
+  // C1: cube through SceneBuilder.addMesh (object-per-triangle path; builder scenes shade grey)
+  const cube = geometry.cube(0.5);
+  const sb = sceneApi.createSceneBuilder();
+  sb.addMesh({ positions: Array.from(cube.positions), indices: Array.from(cube.indices) });
+  const ang = 0.6, eye = [3 * Math.cos(ang), 1.0, 3 * Math.sin(ang)], n = Math.hypot(eye[0], eye[1], eye[2]);
+  const cam = { pos: eye, yaw: Math.atan2(-eye[2], -eye[0]), pitch: Math.asin(-eye[1] / n) };
+  frame('cube', sb.toObject(), cam, 80, 40);
+
+  // C2: icosphere through the typed-array fast path, with two point lights
+  const ico = geometry.icosphere(4, 1.0);
+  const lights = { points: [{ p: [2, 1.5, 0], color: [1, 0.6, 0.5], intensity: 3 }, { p: [-1, 1.5, 1.7], color: [1, 0.7, 0.5], intensity: 3 }] };
+  const f2 = frame('ico', sceneApi.meshScene(ico, { lights }), cam, 640, 360);
+
+  // wrong-sized framebuffer is silently left alone; getPixels returns the last frame
+  const small = new Uint8ClampedArray(16).fill(7);
+  router.renderScene(0.0, small, { cols: 640, rows: 360 });
+  if (!small.every((v) => v === 7)) throw new Error('mismatched framebuffer must stay untouched');
+  const again = new Uint8Array(640 * 360 * 4);
+  router.getPixels({ framebuffer: again, width: 640, height: 360 });
+  if (Buffer.compare(Buffer.from(again.buffer), Buffer.from(f2.fb.buffer)) !== 0) throw new Error('getPixels(flipY) != frame');
+  const raw = router.getPixels({});
+  if (raw[0] !== f2.fb[(359 * 640) * 4]) throw new Error('raw getPixels should be bottom-up');
+
+  // present: UI overrides in alpha (js/main.js:342-361), then AsciiPass.drawFromBuffer
+  const ui = f2.fb.slice();
+  const text = '3.14159 fps';
+  for (let i = 0; i < text.length; i++) { const p = (5 * 640 + 10 + i) * 4; ui[p] = ui[p + 1] = ui[p + 2] = 0; ui[p + 3] = text.charCodeAt(i) & 0xFF; }
+  const pass = new AsciiPass();
+  const codes = pass.drawFromBuffer(ui, 640, 360);
+  dump('ico_ui.rgba', ui); dump('ico_ui.codes', codes);
+  meta.row5 = pass.rowString(5).slice(10, 10 + text.length);
+  pass.dispose();
+
+  // empty scene: early return, buffers untouched (raster.js:274)
+  router.setScene({});
+  const untouched = new Uint8ClampedArray(80 * 40 * 4).fill(9);
+  router.renderScene(0.0, untouched, { cols: 80, rows: 40 });
+  if (!untouched.every((v) => v === 9)) throw new Error('empty scene must not touch the framebuffer');
+
+  // backend switch disposes and replays the scene; dispose is idempotent
+  router.setScene(sceneApi.meshScene(cube));
+  router.setBackend('hip');
+  frame('cube_mesh', sceneApi.meshScene(cube), cam, 96, 36);
+  router.disposeGPU(); router.disposeGPU();
+  fs.writeFileSync(path.join(outDir, 'meta.json'), JSON.stringify(meta));
+  console.log('gpu harness done');
+})().catch((e) => { console.error(e); process.exit(1); });

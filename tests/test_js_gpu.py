@@ -1,0 +1,50 @@
+"""The JavaScript host end to end on the GPU: Node -> router -> HIP backend -> N-API addon -> HIP
+kernels, compared bit for bit with the oracle fed by the Python host mirror."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_node_harness_frames_match_oracle(pkg, oracle, tmp_path):
+    node = shutil.which("node")
+    assert node, "node is required for the JavaScript host"
+    r = subprocess.run([node, os.path.join(ROOT, "tests", "js", "gpu_frame.mjs"), str(tmp_path)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    meta = json.load(open(tmp_path / "meta.json"))
+    assert meta["row5"] == "3.14159 fps"
+    ramp = "@%#*+=-:. "
+    meshes = {
+        "cube": (pkg.geometry.cube(0.5), None),
+        "cube_mesh": (pkg.geometry.cube(0.5), None),
+        "ico": (pkg.geometry.icosphere(4, 1.0),
+                {"lights": {"points": [{"p": [2, 1.5, 0], "color": [1, 0.6, 0.5], "intensity": 3},
+                                       {"p": [-1, 1.5, 1.7], "color": [1, 0.7, 0.5], "intensity": 3}]}}),
+    }
+    for fr in meta["frames"]:
+        (P, I), scene = meshes[fr["name"]]
+        vbo, idx = pkg.host.mesh_to_vbo(P, I)
+        cols, rows = fr["cols"], fr["rows"]
+        proj, view = pkg.host.camera_matrices(fr["cam"], cols, rows, fr["pixelAspect"])
+        lights = pkg.host.pack_lights(scene or {})
+        if fr["name"] == "cube":          # SceneBuilder scenes: ambient = env colour * 0 (raster.js:309-311)
+            lights["ambient"] = np.zeros(3, dtype=np.float32)
+        rgba, depth, _ = oracle.render(vbo, idx, proj, view, lights, cols, rows)
+        asc = oracle.quantize(rgba, cols, rows, ramp, 1, 2, 12)
+        got_rgba = np.fromfile(tmp_path / (fr["name"] + ".rgba"), dtype=np.uint8).reshape(rows, cols, 4)
+        got_depth = np.fromfile(tmp_path / (fr["name"] + ".depth"), dtype=np.float32).reshape(rows, cols)
+        got_ascii = np.fromfile(tmp_path / (fr["name"] + ".ascii"), dtype=np.uint8).reshape(rows, cols)
+        assert np.array_equal(got_rgba, rgba), fr["name"]
+        assert np.array_equal(got_depth.view(np.uint32), depth.view(np.uint32)), fr["name"]
+        assert np.array_equal(got_ascii, asc), fr["name"]
+        assert np.count_nonzero(rgba[:, :, :3]) > 30 and np.count_nonzero(depth < 1.0) > 100
+    ui = np.fromfile(tmp_path / "ico_ui.rgba", dtype=np.uint8)
+    codes = np.fromfile(tmp_path / "ico_ui.codes", dtype=np.uint8).reshape(360, 640)
+    assert np.array_equal(codes, oracle.quantize(ui, 640, 360, ramp, 1, 2, 12))
