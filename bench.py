@@ -121,9 +121,17 @@ def main():
     if rank == 0:
         cells = args.cols * (row1 - row0)
         per_launch_bytes = {                             # algorithmic bytes one launch must move
-            "k_raster": args.tris * 120,                 # 3 x 36 B vertices + 12 B indices per triangle
+            # tiled path: per-frame triangle stream is the derived position planes (36 B) + flat flag (1 B);
+            # per cell RGBA8 4 + depth 4 + ramp index 1 written once, visibility keys stay in LDS
+            "k_setup": args.tris * 37,
+            "k_tile": cells * 9,
+            "k_ascii": cells * 2,                        # ramp index in, ASCII code out
+            "k_fill": counters["bin_records"] * 8,       # one 8-byte entry per (sub-triangle, bin)
+            "k_binscan": 0, "k_binoffsets": 0,           # bookkeeping: no algorithmic traffic of their own
+            # direct path: reference layout, 3 x 36 B vertices + 12 B indices per triangle
+            "k_raster": args.tris * 120,
             "k_shade": cells * 9,                        # RGBA8 + depth f32 + ASCII per cell
-            "k_clear": cells * 8, "k_ascii": cells * 5, "k_raster_medium": 0, "k_raster_large": 0,
+            "k_clear": cells * 8, "k_raster_medium": 0, "k_raster_large": 0,
         }
         kern = {k: {"launches": n, "avg_us": 1e3 * ms / n} for k, (n, ms) in stats.items() if n}
         dom = max(kern, key=lambda k: kern[k]["avg_us"])
