@@ -487,8 +487,8 @@ struct __align__(16) BinRec {
 };
 static_assert(sizeof(BinRec) == 64, "bin records are four 16-byte loads");
 
-// Per-frame binning state, double-buffered by frame parity so that the kernels of frame f can reset
-// the block frame f+1 will use: total[b] entries of bin b.
+// Per-frame binning state; one block per frame parity, like every other buffer the binning kernels
+// write, so that the binning of frame f+1 can run while frame f's tiles are still being resolved.
 struct BinState {
     uint32_t total[kMaxBins];
     uint32_t start[kMaxBins];   // exclusive scan of total (written by k_fill's first workgroup)
@@ -617,7 +617,7 @@ __device__ __forceinline__ BinRec make_record(const Candidate &c, uint32_t id, u
 __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const float *__restrict__ tripos, size_t stride,
                                                          const uint8_t *__restrict__ flat, BinRec *__restrict__ records,
                                                          uint4 *__restrict__ surv, uint32_t *__restrict__ surv_count,
-                                                         uint32_t *__restrict__ dircount, BinState *__restrict__ state) {
+                                                         uint32_t *__restrict__ dircount) {
     __shared__ uint32_t hist[kMaxBins];
     __shared__ uint32_t s_wave[kSetupThreads / 64];
     const uint32_t tid = threadIdx.x;
@@ -625,8 +625,6 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const f
     const uint32_t t_begin = blockIdx.x * fp.chunk;
     const uint32_t t_end = min(t_begin + fp.chunk, fp.n_tris);
     for (int k = int(tid); k < nbins; k += kSetupThreads) hist[k] = 0;
-    BinState &st_next = state[(fp.frame + 1u) & 1u];
-    if (blockIdx.x == 0 && tid == 0) { st_next.overflow = 0; st_next.n_entries = 0; }  // idle values for the next frame
     __syncthreads();
     const int jlo = fp.rows - fp.yb, jhi = fp.rows - 1 - fp.ya;
     const uint32_t loc_base = blockIdx.x * 2u * fp.chunk;
@@ -736,9 +734,10 @@ __global__ __launch_bounds__(1024) void k_binoffsets(FrameParams fp, const uint3
         if (b1 < nbins) boff[size_t(y) * nbins + b1] = r1;
         r0 += x0[y]; r1 += x1[y];
     }
-    if (b0 < nbins) { st.start[b0] = s0; st.total[b0] = t0; if (!ok0 && t0) st.overflow = 1u; }
-    if (b1 < nbins) { st.start[b1] = s1; st.total[b1] = t1; if (!ok1 && t1) st.overflow = 1u; }
-    if (tid == 0) st.n_entries = n_entries;
+    if (b0 < nbins) { st.start[b0] = s0; st.total[b0] = t0; }
+    if (b1 < nbins) { st.start[b1] = s1; st.total[b1] = t1; }
+    const int any_overflow = __syncthreads_or((b0 < nbins && !ok0 && t0) || (b1 < nbins && !ok1 && t1));
+    if (tid == 0) { st.n_entries = n_entries; st.overflow = any_overflow ? 1u : 0u; }
 }
 
 __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const BinRec *__restrict__ records,
@@ -1103,7 +1102,13 @@ thread_local char g_create_error[256] = "";
 
 struct ar_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // pixel stream: tile resolve, shading, ASCII, copies; every output completes here
+    hipStream_t gstream = nullptr;  // geometry stream: setup and binning of the next frame run beside the pixel work
+    hipEvent_t ev_fill[2] = {nullptr, nullptr};  // per buffer set: binning of the frame using it is complete
+    hipEvent_t ev_tile[2] = {nullptr, nullptr};  // per buffer set: the tiles of the frame using it are resolved
+    hipStream_t astream = nullptr;  // ASCII stream: smoothing of frame f beside the tile resolve of frame f+1
+    hipEvent_t ev_ascii[2] = {nullptr, nullptr}; // per ramp-index plane: the smoothing pass that reads it is done
+    bool overlap = true;            // false: everything on the pixel stream
     float *d_vbo = nullptr;
     uint32_t *d_idx = nullptr;
     uint32_t n_verts = 0, n_tris = 0;
@@ -1111,14 +1116,14 @@ struct ar_ctx {
     FrameParams fp;
     int strip0 = 0, strip1 = 0;
     int cols = 0, rows = 0;  // size of the current targets
-    uint64_t *d_vis = nullptr;
+    uint64_t *d_vis[2] = {nullptr, nullptr};  // global key buffers ([0] direct path; tiled path: overflow keys of the frame parity)
     uint8_t *d_rgba = nullptr;
     float *d_depth = nullptr;
     uint8_t *d_ascii = nullptr;
-    uint8_t *d_ridx = nullptr;   // ramp index per cell (input of the smoothing pass)
+    uint8_t *d_ridx[2] = {nullptr, nullptr};  // ramp index per cell (input of the smoothing pass), by frame parity on the tiled path
     uint32_t *d_ids = nullptr;   // winner per cell, allocated when id output is switched on
     bool want_ids = false;
-    bool vis_clean = false;      // every key of d_vis is "background" (k_shade restores this each frame)
+    bool vis_clean = false;      // every key of d_vis[*] is "background" (the consuming kernels restore this each frame)
     TriRec *d_medium = nullptr, *d_large = nullptr;
     uint32_t *d_counters = nullptr;  // [0..1] live queue counters, [2..3] those of the last frame
     // tiled path
@@ -1127,15 +1132,16 @@ struct ar_ctx {
     float *d_tripos = nullptr;       // 9 planes x tripos_stride floats: triangle positions
     size_t tripos_stride = 0;
     float *d_triattr = nullptr;      // n_tris x 24 floats: the three vertices' normals and colours
-    BinRec *d_records = nullptr;     // 2 x n_tris setup record slots, filled densely per k_setup workgroup
+    // everything the binning kernels write exists twice, indexed by frame parity
+    BinRec *d_records[2] = {nullptr, nullptr};  // 2 x n_tris setup record slots, filled densely per k_setup workgroup
     uint8_t *d_flat = nullptr;       // n_tris flags: identical normal and colour at the three vertices
-    uint4 *d_surv = nullptr;         // per k_setup workgroup: (id, cell range, flags) of its surviving sub-triangles
-    uint32_t *d_surv_count = nullptr;
-    uint32_t *d_dircount = nullptr;  // per k_setup workgroup: entries per bin
+    uint4 *d_surv[2] = {nullptr, nullptr};  // per k_setup workgroup: (id, cell range, flags) of its surviving sub-triangles
+    uint32_t *d_surv_count[2] = {nullptr, nullptr};
+    uint32_t *d_dircount[2] = {nullptr, nullptr};  // per k_setup workgroup: entries per bin (+ scan scratch)
     size_t group_cap = 0, dircount_cap = 0;
-    unsigned long long *d_entries = nullptr;  // (id, tile mask) entries grouped by bin
+    unsigned long long *d_entries[2] = {nullptr, nullptr};  // (record slot, tile mask) entries grouped by bin
     uint32_t pool_cap = 0;
-    BinState *d_state = nullptr;     // two blocks used by alternate frames
+    BinState *d_state = nullptr;     // two blocks, indexed by frame parity
     uint32_t frame = 0;              // tiled frames enqueued so far
     bool last_tiled = false;
     uint8_t *d_q_rgba = nullptr, *d_q_ascii = nullptr;
@@ -1175,14 +1181,15 @@ struct Stamper {  // brackets one launch with events when profiling is on
     ar_ctx *ctx;
     hipEvent_t a = nullptr, b = nullptr;
     int slot;
-    Stamper(ar_ctx *c, int s) : ctx(c), slot(s) {
+    hipStream_t stream;
+    Stamper(ar_ctx *c, int s, hipStream_t st = nullptr) : ctx(c), slot(s), stream(st ? st : c->stream) {
         if (!ctx->profiling) return;
         a = take(); b = take();
-        if (a) (void)hipEventRecord(a, ctx->stream);
+        if (a) (void)hipEventRecord(a, stream);
     }
     ~Stamper() {
         if (!ctx->profiling || !a || !b) return;
-        (void)hipEventRecord(b, ctx->stream);
+        (void)hipEventRecord(b, stream);
         ctx->stamps.push_back({a, b, slot});
     }
     hipEvent_t take() {
@@ -1192,11 +1199,18 @@ struct Stamper {  // brackets one launch with events when profiling is on
     }
 };
 
+int sync_streams(ar_ctx *ctx) {
+    AR_HIP(ctx, hipStreamSynchronize(ctx->gstream));
+    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AR_HIP(ctx, hipStreamSynchronize(ctx->astream));
+    return 0;
+}
+
 int free_targets(ar_ctx *ctx) {
-    (void)hipFree(ctx->d_vis); (void)hipFree(ctx->d_rgba); (void)hipFree(ctx->d_depth); (void)hipFree(ctx->d_ascii);
-    (void)hipFree(ctx->d_ridx); (void)hipFree(ctx->d_ids);
-    ctx->d_vis = nullptr; ctx->d_rgba = nullptr; ctx->d_depth = nullptr; ctx->d_ascii = nullptr;
-    ctx->d_ridx = nullptr; ctx->d_ids = nullptr;
+    (void)hipFree(ctx->d_vis[0]); (void)hipFree(ctx->d_vis[1]); (void)hipFree(ctx->d_rgba); (void)hipFree(ctx->d_depth);
+    (void)hipFree(ctx->d_ascii); (void)hipFree(ctx->d_ridx[0]); (void)hipFree(ctx->d_ridx[1]); (void)hipFree(ctx->d_ids);
+    ctx->d_vis[0] = ctx->d_vis[1] = nullptr; ctx->d_rgba = nullptr; ctx->d_depth = nullptr; ctx->d_ascii = nullptr;
+    ctx->d_ridx[0] = ctx->d_ridx[1] = nullptr; ctx->d_ids = nullptr;
     ctx->cols = ctx->rows = 0;
     ctx->rendered = false;
     ctx->vis_clean = false;
@@ -1205,19 +1219,23 @@ int free_targets(ar_ctx *ctx) {
 
 int ensure_targets(ar_ctx *ctx, int cols, int rows) {
     const size_t n = size_t(cols) * rows;
-    if (!(ctx->d_vis && ctx->cols == cols && ctx->rows == rows)) {
-        AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!(ctx->d_vis[0] && ctx->cols == cols && ctx->rows == rows)) {
+        int rc = sync_streams(ctx);
+        if (rc) return rc;
         free_targets(ctx);
-        AR_HIP(ctx, hipMalloc(&ctx->d_vis, n * sizeof(uint64_t)));
+        AR_HIP(ctx, hipMalloc(&ctx->d_vis[0], n * sizeof(uint64_t)));
+        AR_HIP(ctx, hipMalloc(&ctx->d_vis[1], n * sizeof(uint64_t)));
         AR_HIP(ctx, hipMalloc(&ctx->d_rgba, n * 4));
         AR_HIP(ctx, hipMalloc(&ctx->d_depth, n * sizeof(float)));
         AR_HIP(ctx, hipMalloc(&ctx->d_ascii, n));
-        AR_HIP(ctx, hipMalloc(&ctx->d_ridx, n));
+        AR_HIP(ctx, hipMalloc(&ctx->d_ridx[0], n));
+        AR_HIP(ctx, hipMalloc(&ctx->d_ridx[1], n));
         // rows outside a strip are never written by the kernels: give them defined contents once
         AR_HIP(ctx, hipMemsetAsync(ctx->d_rgba, 0, n * 4, ctx->stream));
         AR_HIP(ctx, hipMemsetAsync(ctx->d_depth, 0, n * sizeof(float), ctx->stream));
         AR_HIP(ctx, hipMemsetAsync(ctx->d_ascii, 0, n, ctx->stream));
-        AR_HIP(ctx, hipMemsetAsync(ctx->d_ridx, 0, n, ctx->stream));
+        AR_HIP(ctx, hipMemsetAsync(ctx->d_ridx[0], 0, n, ctx->stream));
+        AR_HIP(ctx, hipMemsetAsync(ctx->d_ridx[1], 0, n, ctx->stream));
         ctx->cols = cols; ctx->rows = rows;
     }
     if (ctx->want_ids && !ctx->d_ids) {
@@ -1261,6 +1279,12 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
     const size_t nbins = size_t(fp.nbx) * fp.nby;
     const bool tiled = ctx->path == 0 && nt <= size_t(kMaxTiles) && nbins <= size_t(kMaxBins) && cols <= 65535 &&
                        rows <= 65535 && ctx->d_tripos;
+    const int set = int(ctx->frame & 1u);  // buffer set of this frame (tiled path)
+    if (tiled != ctx->last_tiled && ctx->rendered) {
+        // the two paths share the key buffers and do not order themselves against each other's streams
+        rc = sync_streams(ctx);
+        if (rc) return rc;
+    }
     if (tiled) {
         // one triangle per k_setup lane and pass; more passes only beyond kMaxGroups workgroups
         uint32_t chunk = (fp.n_tris + kMaxGroups - 1) / kMaxGroups;
@@ -1269,28 +1293,36 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
         fp.n_groups = (fp.n_tris + chunk - 1) / chunk;
         fp.frame = ctx->frame;
         const uint32_t want_cap = ctx->pool_cap_option ? ctx->pool_cap_option : 2u * fp.n_tris + 65536u;
-        if (!ctx->d_entries || ctx->pool_cap != want_cap) {
-            AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            (void)hipFree(ctx->d_entries);
-            ctx->d_entries = nullptr; ctx->pool_cap = 0;
-            AR_HIP(ctx, hipMalloc(&ctx->d_entries, size_t(want_cap) * sizeof(unsigned long long)));
+        if (!ctx->d_entries[0] || ctx->pool_cap != want_cap) {
+            rc = sync_streams(ctx);
+            if (rc) return rc;
+            for (int k = 0; k < 2; k++) { (void)hipFree(ctx->d_entries[k]); ctx->d_entries[k] = nullptr; }
+            ctx->pool_cap = 0;
+            for (int k = 0; k < 2; k++) AR_HIP(ctx, hipMalloc(&ctx->d_entries[k], size_t(want_cap) * sizeof(unsigned long long)));
             ctx->pool_cap = want_cap;
         }
         const size_t want_groups = size_t(fp.n_groups) * 2 * chunk;
-        if (!ctx->d_surv || ctx->group_cap < want_groups) {
-            AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            (void)hipFree(ctx->d_surv); (void)hipFree(ctx->d_surv_count);
-            ctx->d_surv = nullptr; ctx->d_surv_count = nullptr; ctx->group_cap = 0;
-            AR_HIP(ctx, hipMalloc(&ctx->d_surv, want_groups * sizeof(uint4)));
-            AR_HIP(ctx, hipMalloc(&ctx->d_surv_count, (size_t(kMaxGroups) + 1) * sizeof(uint32_t)));
+        if (!ctx->d_surv[0] || ctx->group_cap < want_groups) {
+            rc = sync_streams(ctx);
+            if (rc) return rc;
+            for (int k = 0; k < 2; k++) {
+                (void)hipFree(ctx->d_surv[k]); (void)hipFree(ctx->d_surv_count[k]);
+                ctx->d_surv[k] = nullptr; ctx->d_surv_count[k] = nullptr;
+            }
+            ctx->group_cap = 0;
+            for (int k = 0; k < 2; k++) {
+                AR_HIP(ctx, hipMalloc(&ctx->d_surv[k], want_groups * sizeof(uint4)));
+                AR_HIP(ctx, hipMalloc(&ctx->d_surv_count[k], (size_t(kMaxGroups) + 1) * sizeof(uint32_t)));
+            }
             ctx->group_cap = want_groups;
         }
         const size_t want_dir = size_t(fp.n_groups) * nbins;
-        if (!ctx->d_dircount || ctx->dircount_cap < want_dir) {
-            AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            (void)hipFree(ctx->d_dircount);
-            ctx->d_dircount = nullptr; ctx->dircount_cap = 0;
-            AR_HIP(ctx, hipMalloc(&ctx->d_dircount, (want_dir + 32 * size_t(kMaxBins)) * sizeof(uint32_t)));
+        if (!ctx->d_dircount[0] || ctx->dircount_cap < want_dir) {
+            rc = sync_streams(ctx);
+            if (rc) return rc;
+            for (int k = 0; k < 2; k++) { (void)hipFree(ctx->d_dircount[k]); ctx->d_dircount[k] = nullptr; }
+            ctx->dircount_cap = 0;
+            for (int k = 0; k < 2; k++) AR_HIP(ctx, hipMalloc(&ctx->d_dircount[k], (want_dir + 32 * size_t(kMaxBins)) * sizeof(uint32_t)));
             ctx->dircount_cap = want_dir;
         }
     }
@@ -1298,65 +1330,93 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
     ctx->vis_clean = false;  // stays false if anything below fails: the next frame then starts from scratch
     if (!was_clean) {
         // first frame on these targets (or after a failed one).  In steady state every kernel that
-        // consumes a visibility key, a queue counter or a binning state word puts it back to its
-        // idle value, so no per-frame clear is needed.
+        // consumes a visibility key or a queue counter puts it back to its idle value, so no per-frame
+        // clear is needed.
+        rc = sync_streams(ctx);
+        if (rc) return rc;
         AR_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
         AR_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, 2 * sizeof(BinState), ctx->stream));
-        Stamper s(ctx, K_CLEAR);
-        k_clear<<<2048, 256, 0, ctx->stream>>>(ctx->d_vis, 0, size_t(cols) * rows);
+        {
+            Stamper s(ctx, K_CLEAR);
+            k_clear<<<2048, 256, 0, ctx->stream>>>(ctx->d_vis[0], 0, size_t(cols) * rows);
+            k_clear<<<2048, 256, 0, ctx->stream>>>(ctx->d_vis[1], 0, size_t(cols) * rows);
+        }
+        AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     if (tiled) {
+        // Binning of frame f runs on the geometry stream and may overlap the pixel work of frame f-1;
+        // it only has to wait until the tiles of frame f-2 (the last user of this buffer set) are done.
+        hipStream_t gs = ctx->overlap ? ctx->gstream : ctx->stream;
+        uint32_t *dircount = ctx->d_dircount[set];
+        uint32_t *blocksum = dircount + ctx->dircount_cap, *boff = blocksum + 16 * size_t(kMaxBins);
+        if (ctx->overlap) AR_HIP(ctx, hipStreamWaitEvent(gs, ctx->ev_tile[set], 0));
         {
-            Stamper s(ctx, K_SETUP);
-            k_setup<<<fp.n_groups, kSetupThreads, 0, ctx->stream>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_flat, ctx->d_records, ctx->d_surv,
-                                                                   ctx->d_surv_count, ctx->d_dircount, ctx->d_state);
+            Stamper s(ctx, K_SETUP, gs);
+            k_setup<<<fp.n_groups, kSetupThreads, 0, gs>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_flat, ctx->d_records[set],
+                                                         ctx->d_surv[set], ctx->d_surv_count[set], dircount);
         }
         {
-            Stamper s(ctx, K_BINSCAN);
-            k_binscan<<<dim3(unsigned((nbins + 63) / 64), 16), 1024, 0, ctx->stream>>>(fp, ctx->d_dircount, ctx->d_dircount + ctx->dircount_cap);
-        }
-        uint32_t *blocksum = ctx->d_dircount + ctx->dircount_cap, *boff = blocksum + 16 * size_t(kMaxBins);
-        {
-            Stamper s(ctx, K_BINOFF);
-            k_binoffsets<<<1, 1024, 0, ctx->stream>>>(fp, blocksum, boff, ctx->d_state, ctx->pool_cap);
+            Stamper s(ctx, K_BINSCAN, gs);
+            k_binscan<<<dim3(unsigned((nbins + 63) / 64), 16), 1024, 0, gs>>>(fp, dircount, blocksum);
         }
         {
-            Stamper s(ctx, K_FILL);
-            k_fill<<<fp.n_groups, kSetupThreads, 0, ctx->stream>>>(fp, ctx->d_records, ctx->d_surv, ctx->d_surv_count, ctx->d_dircount, boff,
-                                                                  ctx->d_state, ctx->d_entries, ctx->pool_cap, ctx->d_vis);
+            Stamper s(ctx, K_BINOFF, gs);
+            k_binoffsets<<<1, 1024, 0, gs>>>(fp, blocksum, boff, ctx->d_state, ctx->pool_cap);
+        }
+        {
+            Stamper s(ctx, K_FILL, gs);
+            k_fill<<<fp.n_groups, kSetupThreads, 0, gs>>>(fp, ctx->d_records[set], ctx->d_surv[set], ctx->d_surv_count[set], dircount, boff,
+                                                        ctx->d_state, ctx->d_entries[set], ctx->pool_cap, ctx->d_vis[set]);
+        }
+        if (ctx->overlap) {
+            AR_HIP(ctx, hipEventRecord(ctx->ev_fill[set], gs));
+            AR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fill[set], 0));
+            AR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_ascii[set], 0));  // ridx[set] was read by frame f-2's smoothing
+            if (fp.mode_on != 1)  // k_tile writes the ASCII plane itself: not before the previous frame's smoothing has
+                AR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_ascii[set ^ 1], 0));
         }
         {
             Stamper s(ctx, K_TILE);
             k_tile<<<unsigned(nt), 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_tripos, ctx->tripos_stride,
-                                                         ctx->d_records, ctx->d_entries,
-                                                         ctx->pool_cap, ctx->d_state, ctx->d_vis, ctx->d_rgba, ctx->d_depth,
-                                                         ctx->d_ascii, ctx->d_ridx, ctx->d_ids);
+                                                         ctx->d_records[set], ctx->d_entries[set], ctx->pool_cap, ctx->d_state,
+                                                         ctx->d_vis[set], ctx->d_rgba, ctx->d_depth, ctx->d_ascii, ctx->d_ridx[set],
+                                                         ctx->d_ids);
         }
+        if (ctx->overlap) AR_HIP(ctx, hipEventRecord(ctx->ev_tile[set], ctx->stream));
         ctx->frame++;
     } else {
         {
             Stamper s(ctx, K_RASTER);
-            k_raster<<<(fp.n_tris + 255) / 256, 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_vis, ctx->d_medium,
+            k_raster<<<(fp.n_tris + 255) / 256, 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_vis[0], ctx->d_medium,
                                                                       ctx->d_large, ctx->d_counters);
         }
         {
             Stamper s(ctx, K_MEDIUM);
-            k_raster_medium<<<512, 256, 0, ctx->stream>>>(fp, ctx->d_vis, ctx->d_medium, ctx->d_counters);
+            k_raster_medium<<<512, 256, 0, ctx->stream>>>(fp, ctx->d_vis[0], ctx->d_medium, ctx->d_counters);
         }
         {
             Stamper s(ctx, K_LARGE);
             dim3 grid((cols + 15) / 16, (fp.yb - fp.ya + 15) / 16);
-            k_raster_large<<<grid, 256, 0, ctx->stream>>>(fp, ctx->d_vis, ctx->d_large, ctx->d_counters);
+            k_raster_large<<<grid, 256, 0, ctx->stream>>>(fp, ctx->d_vis[0], ctx->d_large, ctx->d_counters);
         }
         {
             Stamper s(ctx, K_SHADE);
-            k_shade<<<cell_blocks, 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_vis, ctx->d_rgba, ctx->d_depth,
-                                                         ctx->d_ascii, ctx->d_ridx, ctx->d_ids, ctx->d_counters);
+            k_shade<<<cell_blocks, 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_vis[0], ctx->d_rgba, ctx->d_depth,
+                                                         ctx->d_ascii, ctx->d_ridx[0], ctx->d_ids, ctx->d_counters);
         }
     }
     if (fp.mode_on == 1) {
-        Stamper s(ctx, K_ASCII);
-        launch_ascii<false>(fp, ctx->d_ridx, ctx->d_ascii, ctx->stream);
+        if (tiled && ctx->overlap) {
+            AR_HIP(ctx, hipStreamWaitEvent(ctx->astream, ctx->ev_tile[set], 0));
+            {
+                Stamper s(ctx, K_ASCII, ctx->astream);
+                launch_ascii<false>(fp, ctx->d_ridx[set], ctx->d_ascii, ctx->astream);
+            }
+            AR_HIP(ctx, hipEventRecord(ctx->ev_ascii[set], ctx->astream));
+        } else {
+            Stamper s(ctx, K_ASCII);
+            launch_ascii<false>(fp, ctx->d_ridx[tiled ? set : 0], ctx->d_ascii, ctx->stream);
+        }
     }
     AR_HIP(ctx, hipGetLastError());
     ctx->vis_clean = true;
@@ -1378,6 +1438,14 @@ ar_ctx *ar_create(int device_id) {
     if (!ctx) { fail(nullptr, AR_E_NOMEM, "out of host memory"); return nullptr; }
     ctx->device = device_id;
     bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&ctx->astream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_ascii[0], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_ascii[1], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_fill[0], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_fill[1], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_tile[0], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_tile[1], hipEventDisableTiming) == hipSuccess &&
               hipMalloc(&ctx->d_medium, size_t(kMediumCapacity) * sizeof(TriRec)) == hipSuccess &&
               hipMalloc(&ctx->d_large, size_t(kLargeCapacity) * sizeof(TriRec)) == hipSuccess &&
               hipMalloc(&ctx->d_counters, 4 * sizeof(uint32_t)) == hipSuccess &&
@@ -1403,16 +1471,25 @@ ar_ctx *ar_create(int device_id) {
 void ar_destroy(ar_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->gstream) (void)hipStreamSynchronize(ctx->gstream);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->astream) (void)hipStreamSynchronize(ctx->astream);
     for (auto &s : ctx->stamps) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
     free_targets(ctx);
     (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx);
     (void)hipFree(ctx->d_medium); (void)hipFree(ctx->d_large); (void)hipFree(ctx->d_counters);
     (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii);
-    (void)hipFree(ctx->d_entries); (void)hipFree(ctx->d_state); (void)hipFree(ctx->d_surv); (void)hipFree(ctx->d_surv_count);
-    (void)hipFree(ctx->d_dircount); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr); (void)hipFree(ctx->d_records);
-    (void)hipFree(ctx->d_flat);
+    (void)hipFree(ctx->d_state); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr); (void)hipFree(ctx->d_flat);
+    for (int k = 0; k < 2; k++) {
+        (void)hipFree(ctx->d_entries[k]); (void)hipFree(ctx->d_surv[k]); (void)hipFree(ctx->d_surv_count[k]);
+        (void)hipFree(ctx->d_dircount[k]); (void)hipFree(ctx->d_records[k]);
+        if (ctx->ev_fill[k]) (void)hipEventDestroy(ctx->ev_fill[k]);
+        if (ctx->ev_tile[k]) (void)hipEventDestroy(ctx->ev_tile[k]);
+        if (ctx->ev_ascii[k]) (void)hipEventDestroy(ctx->ev_ascii[k]);
+    }
+    if (ctx->gstream) (void)hipStreamDestroy(ctx->gstream);
+    if (ctx->astream) (void)hipStreamDestroy(ctx->astream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1424,10 +1501,12 @@ int ar_set_mesh(ar_ctx *ctx, const float *vbo9, uint32_t n_verts, const uint32_t
     if (n_tris > 0x7FFFFFFFu) return fail(ctx, AR_E_ARG, "ar_set_mesh: too many triangles (%u)", n_tris);
     if (n_tris && (!vbo9 || !idx || !n_verts)) return fail(ctx, AR_E_ARG, "ar_set_mesh: null buffer with %u triangles", n_tris);
     AR_HIP(ctx, hipSetDevice(ctx->device));
-    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = sync_streams(ctx);
+    if (rc) return rc;
     (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr);
-    (void)hipFree(ctx->d_records); (void)hipFree(ctx->d_flat);
-    ctx->d_vbo = nullptr; ctx->d_idx = nullptr; ctx->d_tripos = nullptr; ctx->d_triattr = nullptr; ctx->d_records = nullptr;
+    (void)hipFree(ctx->d_records[0]); (void)hipFree(ctx->d_records[1]); (void)hipFree(ctx->d_flat);
+    ctx->d_vbo = nullptr; ctx->d_idx = nullptr; ctx->d_tripos = nullptr; ctx->d_triattr = nullptr;
+    ctx->d_records[0] = ctx->d_records[1] = nullptr;
     ctx->d_flat = nullptr;
     ctx->n_verts = 0; ctx->n_tris = 0;
     if (!n_tris) return 0;
@@ -1439,7 +1518,7 @@ int ar_set_mesh(ar_ctx *ctx, const float *vbo9, uint32_t n_verts, const uint32_t
     ctx->tripos_stride = (size_t(n_tris) + 63) / 64 * 64;
     AR_HIP(ctx, hipMalloc(&ctx->d_tripos, 9 * ctx->tripos_stride * sizeof(float)));
     AR_HIP(ctx, hipMalloc(&ctx->d_triattr, size_t(n_tris) * 24 * sizeof(float)));
-    AR_HIP(ctx, hipMalloc(&ctx->d_records, 2 * size_t(n_tris) * sizeof(BinRec)));
+    for (int k = 0; k < 2; k++) AR_HIP(ctx, hipMalloc(&ctx->d_records[k], 2 * size_t(n_tris) * sizeof(BinRec)));
     AR_HIP(ctx, hipMalloc(&ctx->d_flat, size_t(n_tris)));
     k_tristream<<<(n_tris + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_vbo, ctx->d_idx, n_verts, n_tris, ctx->tripos_stride, ctx->d_tripos,
                                                               ctx->d_triattr, ctx->d_flat);
@@ -1500,15 +1579,15 @@ int ar_render_async(ar_ctx *ctx, int cols, int rows) {
 int ar_sync(ar_ctx *ctx) {
     if (!ctx) return AR_E_ARG;
     AR_HIP(ctx, hipSetDevice(ctx->device));
-    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return sync_streams(ctx);
 }
 
 int ar_read(ar_ctx *ctx, uint8_t *rgba, float *depth, uint8_t *ascii, uint32_t *ids) {
     if (!ctx) return AR_E_ARG;
     if (!ctx->rendered) return fail(ctx, AR_E_STATE, "ar_read: no frame has been rendered at this grid size");
     AR_HIP(ctx, hipSetDevice(ctx->device));
-    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = sync_streams(ctx);
+    if (rc) return rc;
     const size_t n = size_t(ctx->cols) * ctx->rows;
     if (rgba) AR_HIP(ctx, hipMemcpy(rgba, ctx->d_rgba, n * 4, hipMemcpyDeviceToHost));
     if (depth) AR_HIP(ctx, hipMemcpy(depth, ctx->d_depth, n * sizeof(float), hipMemcpyDeviceToHost));
@@ -1583,7 +1662,8 @@ int ar_set_profiling(ar_ctx *ctx, int on) {
 int ar_kernel_stats(ar_ctx *ctx, const char *names[AR_N_KERNELS], uint32_t launches[AR_N_KERNELS], float total_ms[AR_N_KERNELS]) {
     if (!ctx) return AR_E_ARG;
     AR_HIP(ctx, hipSetDevice(ctx->device));
-    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = sync_streams(ctx);
+    if (rc) return rc;
     for (int k = 0; k < AR_N_KERNELS; k++) {
         if (names) names[k] = kKernelNames[k];
         if (launches) launches[k] = 0;
@@ -1605,7 +1685,8 @@ int ar_kernel_stats(ar_ctx *ctx, const char *names[AR_N_KERNELS], uint32_t launc
 int ar_frame_counters(ar_ctx *ctx, uint32_t out[8]) {
     if (!ctx || !out) return AR_E_ARG;
     AR_HIP(ctx, hipSetDevice(ctx->device));
-    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = sync_streams(ctx);
+    if (rc) return rc;
     uint32_t c[4] = {0, 0, 0, 0}, last[2] = {0, 0};  // last: {overflow, n_entries} of the last tiled frame
     AR_HIP(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
     AR_HIP(ctx, hipMemcpy(last, &ctx->d_state[(ctx->frame + 1u) & 1u].overflow, sizeof last, hipMemcpyDeviceToHost));
@@ -1626,6 +1707,13 @@ int ar_set_option(ar_ctx *ctx, int option, long long value) {
             if (value != 0 && value != 1) return fail(ctx, AR_E_ARG, "AR_OPT_PATH takes 0 (tiled) or 1 (direct)");
             ctx->path = int(value);
             return 0;
+        case AR_OPT_OVERLAP: {
+            if (value != 0 && value != 1) return fail(ctx, AR_E_ARG, "AR_OPT_OVERLAP takes 0 or 1");
+            int rc = sync_streams(ctx);
+            if (rc) return rc;
+            ctx->overlap = value != 0;
+            return 0;
+        }
         case AR_OPT_POOL_RECORDS:
             if (value < 0 || value > 0x7FFFFFFFll) return fail(ctx, AR_E_ARG, "AR_OPT_POOL_RECORDS out of range");
             ctx->pool_cap_option = uint32_t(value);

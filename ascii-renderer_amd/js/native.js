@@ -25,3 +25,4 @@ export function native() {
 // ar_set_option ids (include/ascii_rast.h)
 export const AR_OPT_PATH = 1;
 export const AR_OPT_POOL_RECORDS = 2;
+export const AR_OPT_OVERLAP = 3;

@@ -109,12 +109,16 @@ int ar_frame_counters(ar_ctx *ctx, uint32_t out[8]);
 
 /* Tuning / test switches (no counterpart in the reference).
  *   AR_OPT_PATH          0 (default): tile-binned path whenever the grid has at most 8000 tiles of
- *                        64x32 cells (512 bins of 4x4 tiles), else the direct path; 1: always the direct path (every
+ *                        64x32 cells, else the direct path; 1: always the direct path (every
  *                        fragment resolved with a 64-bit atomic min in HBM).
+ *   AR_OPT_OVERLAP       1 (default): the tiled path runs triangle setup and binning of a frame on a second
+ *                        stream, so that consecutive ar_render_async frames overlap (setup of frame f+1 beside
+ *                        the tile resolve of frame f); 0: one stream, frames strictly one after the other.
  *   AR_OPT_POOL_RECORDS  capacity of the tiled path's (sub-triangle, bin) entry pool in entries;
  *                        0 (default) sizes it as 2 x triangles + 65536. */
 #define AR_OPT_PATH 1
 #define AR_OPT_POOL_RECORDS 2
+#define AR_OPT_OVERLAP 3
 int ar_set_option(ar_ctx *ctx, int option, long long value);
 
 #ifdef __cplusplus

@@ -142,6 +142,43 @@ def test_pool_overflow_falls_back_and_stays_exact(pkg, oracle):
         r.close()
 
 
+def test_back_to_back_frames_overlap_without_interfering(pkg, oracle):
+    """Frames enqueued without waiting in between run on three streams (setup of frame f+1 beside the
+    tiles of frame f beside the smoothing of frame f-1).  Every frame of a burst with a different
+    camera, alternating smoothing on/off and a pool that overflows must still match the oracle - the
+    burst is replayed so that each of its frames is the last one once, and read back then."""
+    r = pkg.Renderer(0)
+    try:
+        cols, rows = 640, 360
+        sc = pkg.scenes.random_scene(200_000, cols, rows, mesh_grid=(cols, rows))
+        pkg.scenes.upload(r, sc)
+        cams = [{"pos": (0.0, 0.0, 0.0), "yaw": 0.02 * k, "pitch": 0.01 * k} for k in range(5)]
+        modes = [(True, 2, 12), (False, 2, 12), (True, 1, 5), (True, 2, 12), (False, 2, 12)]
+        expect = []
+        for cam, mode in zip(cams, modes):
+            proj, view = pkg.host.camera_matrices(cam, cols, rows, 1.0)
+            rgba, depth, _ = oracle.render(sc["vbo"], sc["idx"], proj, view, sc["lights"], cols, rows)
+            expect.append((proj, view, rgba, depth, oracle.quantize(rgba, cols, rows, pkg.scenes.DEFAULT_RAMP, int(mode[0]), mode[1], mode[2])))
+        for pool in (0, 20_000):
+            r.set_option("pool_records", pool)
+            for overlap in (1, 0):
+                r.set_option("overlap", overlap)
+                for last in range(len(cams)):
+                    for k in range(last + 1):
+                        r.set_camera(expect[k][0], expect[k][1])
+                        r.set_ascii(pkg.scenes.DEFAULT_RAMP, *modes[k])
+                        r.render_async(cols, rows)
+                    out = r.read()
+                    _p, _v, rgba, depth, asc = expect[last]
+                    tag = "pool %d overlap %d burst %d" % (pool, overlap, last)
+                    assert np.array_equal(out["rgba"], rgba), tag
+                    assert np.array_equal(out["depth"].view(np.uint32), depth.view(np.uint32)), tag
+                    assert np.array_equal(out["ascii"], asc), tag
+            assert r.frame_counters()["pool_overflow"] == (1 if pool else 0)
+    finally:
+        r.close()
+
+
 def test_many_tiles_take_the_direct_path(pkg, oracle):
     """More than 8000 tiles (here 8192 x 2048 cells = 8192 tiles): the library falls back to the direct path."""
     r = pkg.Renderer(0)
