@@ -1087,13 +1087,95 @@ __global__ __launch_bounds__(256) void k_ascii(FrameParams fp, const void *__res
     ascii[cell] = (fin >= 0 && fin < fp.ramp_len) ? fp.ramp[fin] : uint8_t(32);
 }
 
+// Modal smoothing over a plane of ramp indices (what rendered frames produce: no override cells).
+// A workgroup takes 128 x 8 cells, a lane four consecutive cells of one row.  The tile and its halo are
+// staged as bytes with rows padded so that a lane's window (its four cells and R neighbours on either
+// side) is three aligned dwords per row: 3 * (2R + 1) LDS reads serve four cells, and the neighbours are
+// byte fields of registers.  Same Boyer-Moore order and vote rule as k_ascii.
+template <int R>
+__global__ __launch_bounds__(256) void k_ascii_plane(FrameParams fp, const uint8_t *__restrict__ src, uint8_t *__restrict__ ascii) {
+    constexpr int TWD = 34, TH = 8 + 2 * R;  // dwords per tile row: 4 bytes of left halo, 128 cells, 4 of right halo
+    __shared__ uint32_t tile[TWD * TH];
+    __shared__ uint8_t ramp[AR_MAX_RAMP];
+    const int x0 = int(blockIdx.x) * 128, y0 = fp.row0 + int(blockIdx.y) * 8;
+    ramp[threadIdx.x] = fp.ramp[threadIdx.x];
+    const bool cols4 = (fp.cols & 3) == 0;
+    for (int k = int(threadIdx.x); k < TWD * TH; k += 256) {
+        const int ty = k / TWD, td = k - ty * TWD;
+        const int gy = min(max(y0 + ty - R, 0), fp.rows - 1);
+        const int gx = x0 - 4 + 4 * td;  // column of the dword's first byte
+        const uint8_t *row = src + size_t(gy) * fp.cols;
+        uint32_t v;
+        if (cols4 && gx >= 0 && gx + 3 < fp.cols) {
+            v = *reinterpret_cast<const uint32_t *>(row + gx);
+        } else {
+            v = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) v |= uint32_t(row[min(max(gx + q, 0), fp.cols - 1)]) << (8 * q);
+        }
+        tile[k] = v;
+    }
+    __syncthreads();
+    const int lx = int(threadIdx.x & 31u), ly = int(threadIdx.x >> 5);
+    const int x = x0 + 4 * lx, y = y0 + ly;
+    if (x >= fp.cols || y >= fp.row1) return;
+    uint32_t w[2 * R + 1][3];
+#pragma unroll
+    for (int dy = -R; dy <= R; dy++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) w[dy + R][q] = tile[(ly + R + dy) * TWD + lx + q];
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        // byte p of a window row is column x - 4 + p; cell j sits at p = 4 + j
+        int cand = -1, cnt = 0, votes = 0;
+#pragma unroll
+        for (int dy = -R; dy <= R; dy++)
+#pragma unroll
+            for (int dx = -R; dx <= R; dx++) {
+                if (dx == 0 && dy == 0) continue;
+                const int p = 4 + j + dx;
+                const int ni = int((w[dy + R][p >> 2] >> (8 * (p & 3))) & 255u);
+                cand = cnt == 0 ? ni : cand;
+                cnt += ni == cand ? 1 : -1;
+            }
+#pragma unroll
+        for (int dy = -R; dy <= R; dy++)
+#pragma unroll
+            for (int dx = -R; dx <= R; dx++) {
+                if (dx == 0 && dy == 0) continue;
+                const int p = 4 + j + dx;
+                votes += int((w[dy + R][p >> 2] >> (8 * (p & 3))) & 255u) == cand ? 1 : 0;
+            }
+        const int base = int((w[R][(4 + j) >> 2] >> (8 * ((4 + j) & 3))) & 255u);
+        const int fin = (votes >= fp.mode_thresh && cand != base) ? cand : base;
+        out |= uint32_t(fin < fp.ramp_len ? ramp[fin] : uint8_t(32)) << (8 * j);
+    }
+    uint8_t *dst = ascii + size_t(y) * fp.cols + x;
+    if (cols4) {
+        *reinterpret_cast<uint32_t *>(dst) = out;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (x + j < fp.cols) dst[j] = uint8_t(out >> (8 * j));
+    }
+}
+
 template <bool FROM_RGBA>
 void launch_ascii(const FrameParams &fp, const void *src, uint8_t *ascii, hipStream_t stream) {
-    const dim3 grid((fp.cols + 31) / 32, (fp.row1 - fp.row0 + 7) / 8);
     const int radius = fp.mode_radius < 1 ? 1 : (fp.mode_radius > 3 ? 3 : fp.mode_radius);  // shader clamps to 1..3
-    if (radius == 1) k_ascii<1, FROM_RGBA><<<grid, 256, 0, stream>>>(fp, src, ascii);
-    else if (radius == 2) k_ascii<2, FROM_RGBA><<<grid, 256, 0, stream>>>(fp, src, ascii);
-    else k_ascii<3, FROM_RGBA><<<grid, 256, 0, stream>>>(fp, src, ascii);
+    if constexpr (!FROM_RGBA) {
+        const dim3 grid((fp.cols + 127) / 128, (fp.row1 - fp.row0 + 7) / 8);
+        const uint8_t *plane = static_cast<const uint8_t *>(src);
+        if (radius == 1) k_ascii_plane<1><<<grid, 256, 0, stream>>>(fp, plane, ascii);
+        else if (radius == 2) k_ascii_plane<2><<<grid, 256, 0, stream>>>(fp, plane, ascii);
+        else k_ascii_plane<3><<<grid, 256, 0, stream>>>(fp, plane, ascii);
+    } else {
+        const dim3 grid((fp.cols + 31) / 32, (fp.row1 - fp.row0 + 7) / 8);
+        if (radius == 1) k_ascii<1, FROM_RGBA><<<grid, 256, 0, stream>>>(fp, src, ascii);
+        else if (radius == 2) k_ascii<2, FROM_RGBA><<<grid, 256, 0, stream>>>(fp, src, ascii);
+        else k_ascii<3, FROM_RGBA><<<grid, 256, 0, stream>>>(fp, src, ascii);
+    }
 }
 
 thread_local char g_create_error[256] = "";

@@ -115,6 +115,13 @@ def main():
     for _ in range(args.steps):
         R.render_async(args.cols, args.rows)
     stats = R.kernel_stats()
+    # and once more with the frames strictly one after the other (no overlap between the kernels of
+    # consecutive frames): each kernel's duration when it has the GPU to itself
+    R.set_option("overlap", 0)
+    for _ in range(args.steps):
+        R.render_async(args.cols, args.rows)
+    stats_serial = R.kernel_stats()
+    R.set_option("overlap", 1)
     R.set_profiling(False)
     counters = R.frame_counters()
 
@@ -157,6 +164,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic},
             "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
+            "kernels_avg_us_serial": {k: round(1e3 * ms / n, 2) for k, (n, ms) in stats_serial.items() if n},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ar, sc)

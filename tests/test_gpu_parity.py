@@ -60,6 +60,14 @@ def test_c2_icosphere_point_lights_and_other_ramps(pkg, oracle, R):
     _check(pkg, oracle, R, sc, ramp="ab", mode=(True, 1, 5))
 
 
+def test_odd_grid_sizes_and_every_smoothing_radius(pkg, oracle, R):
+    """Grids whose width is not a multiple of 4 / 32 / 64 / 128 and heights not a multiple of 8 / 32."""
+    for (cols, rows), mode in (((333, 77), (True, 1, 4)), ((130, 9), (True, 2, 12)), ((127, 33), (True, 3, 20)),
+                               ((5, 3), (True, 2, 12)), ((1, 1), (True, 2, 12)), ((257, 130), (True, 2, 9))):
+        sc = pkg.scenes.icosphere_scene(angle=0.7, cols=cols, rows=rows, subdiv=3)
+        _check(pkg, oracle, R, sc, mode=mode, label="ico %dx%d r%d" % (cols, rows, mode[1]))
+
+
 def test_reference_scenes_from_fixture(pkg, oracle, R, golden_dir):
     """Scenes of the golden fixture: the reference's default scene (two spheres) and a legacy-format
     scene with planes (huge triangles that cross the near plane), spheres and ten point lights."""
