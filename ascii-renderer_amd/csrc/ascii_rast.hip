@@ -842,35 +842,46 @@ __device__ __forceinline__ void shade_from_record(const FrameParams &fp, const f
 
 // Scans rows [r0, r1] x columns [i0, i1] (at most 64 columns) of one record into the LDS key tile.
 // Most cells of a cell range lie outside the triangle, and lanes of a wavefront walk ranges of very
-// different sizes, so the scan is split in two: (1) a cheap pass classifies every cell with a binary32
-// evaluation of the three edge functions and a conservative error band and sets a bit for each cell
-// that is not certainly outside; (2) only those cells pay for the binary64 evaluation that decides
-// coverage and feeds the depth.  The result is exactly that of testing every cell in binary64, but a
-// wavefront executes the expensive path a few times instead of once per cell of its largest range.
-// |e32 - E| <= 2^-22 (|a px| + |r|) for e32 = fl(fl(a32 px) + r32); the band used is 16 times wider.
+// different sizes, so the scan is split in two: (1) per row, each edge function is evaluated in
+// binary32 and solved for the column where it crosses a conservative error band, which gives the
+// interval of columns that are not certainly outside - a run of bits in a 64-cell candidate mask;
+// (2) only those cells pay for the binary64 evaluation that decides coverage and feeds the depth.
+// The result is exactly that of testing every cell in binary64.
+// Band: with a32 = fl(a), r32 = fl(b py + c), |a32 px + r32 - E| <= 2^-24 (|a| px + |r|) (1 + eps); a cell
+// with E >= 0 therefore has a32 px + r32 >= -band / 32 for band = 2^-18 (|a32| px_max + |r32|), and lies
+// beyond the crossing column x of "a32 px + r32 = -band" by at least 0.8 band / |a32| >= 2^-19 |x|, far more
+// than the 2^-22 |x| the binary32 evaluation of x can be off.  Edges with a32 == 0 (or an overflowing
+// reciprocal) put no bound on the interval.
 __device__ __forceinline__ void raster_range(const FrameParams &fp, const Edges &ed, uint32_t key_low, int i0, int i1,
                                              int r0, int r1, int tx0, int tr0, uint64_t *keys) {
     constexpr float kBand = 1.0f / 262144.0f;  // 2^-18
     const float a32[3] = {float(ed.a[0]), float(ed.a[1]), float(ed.a[2])};
-    const float px_max = float(i1 + 1);
+    const float inv_a[3] = {1.0f / a32[0], 1.0f / a32[1], 1.0f / a32[2]};
+    const float apx[3] = {fabsf(a32[0]) * float(i1 + 1), fabsf(a32[1]) * float(i1 + 1), fabsf(a32[2]) * float(i1 + 1)};
     const int w = i1 - i0 + 1;
     const int rows_per_chunk = max(1, 64 / w);
     const float inv_w = 1.0f / float(w);
+    const float flo = float(i0), fhi = float(i1);
     for (int rc = r0; rc <= r1; rc += rows_per_chunk) {
         const int rc1 = min(rc + rows_per_chunk - 1, r1);
         unsigned long long cand = 0ull;
         for (int rr = rc; rr <= rc1; rr++) {
             const double py = double(fp.rows - 1 - rr) + 0.5;
-            const float r32[3] = {float(ed.b[0] * py + ed.c[0]), float(ed.b[1] * py + ed.c[1]), float(ed.b[2] * py + ed.c[2])};
-            const float band[3] = {kBand * (fabsf(a32[0]) * px_max + fabsf(r32[0])), kBand * (fabsf(a32[1]) * px_max + fabsf(r32[1])),
-                                   kBand * (fabsf(a32[2]) * px_max + fabsf(r32[2]))};
-            unsigned long long bit = 1ull << ((rr - rc) * w);
-            for (int i = i0; i <= i1; i++, bit <<= 1) {
-                const float px32 = float(i) + 0.5f;
-                const bool out = a32[0] * px32 + r32[0] < -band[0] || a32[1] * px32 + r32[1] < -band[1] ||
-                                 a32[2] * px32 + r32[2] < -band[2];
-                if (!out) cand |= bit;
+            float lo = flo, hi = fhi;  // candidate columns, as cell indices
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float r32 = float(ed.b[k] * py + ed.c[k]);
+                const float band = kBand * (apx[k] + fabsf(r32));
+                const float x = (-band - r32) * inv_a[k] - 0.5f;  // crossing column as a cell index
+                lo = fmaxf(lo, a32[k] > 0.0f ? x : flo);
+                hi = fminf(hi, a32[k] < 0.0f ? x : fhi);
             }
+            if (!(lo <= hi)) continue;
+            const int ilo = int(ceilf(lo)), ihi = int(floorf(hi));
+            const int n = ihi - ilo + 1;
+            if (n <= 0) continue;
+            const unsigned long long run = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+            cand |= run << ((rr - rc) * w + (ilo - i0));
         }
         while (cand) {
             const int k = __ffsll((long long)cand) - 1;

@@ -1,16 +1,27 @@
-"""Times the frame kernels of a library variant (AR_LIB=path) on the C3 workload; no parity check."""
-import importlib, os, sys, json
+"""Times a library variant (AR_LIB=path) on the C3 workload: frames/s with and without frame overlap,
+and per-kernel durations with the frames run one after the other.  No parity check."""
+import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ar = importlib.import_module("ascii-renderer_amd")
 if os.environ.get("AR_LIB"):
     ar.binding.LIB_PATH = os.environ["AR_LIB"]
 tris = int(os.environ.get("AR_TRIS", "1000000")); cols = int(os.environ.get("AR_COLS", "1920")); rows = int(os.environ.get("AR_ROWS", "1080"))
-sc = ar.scenes.random_scene(tris, cols, rows)
+sc = ar.scenes.random_scene(tris, cols, rows, point_lights=bool(os.environ.get("AR_PL")))
 R = ar.Renderer(0)
 ar.scenes.upload(R, sc)
-for _ in range(10): R.render_async(cols, rows)
-R.sync()
+res = {}
+for ov in (1, 0):
+    R.set_option("overlap", ov)
+    for _ in range(20): R.render_async(cols, rows)
+    R.sync()
+    best = 0.0
+    for rep in range(3):
+        t0 = time.perf_counter(); n = 200
+        for _ in range(n): R.render_async(cols, rows)
+        R.sync()
+        best = max(best, n / (time.perf_counter() - t0))
+    res["fps_overlap%d" % ov] = round(best, 1)
 R.set_profiling(True); R.kernel_stats()
 for _ in range(100): R.render_async(cols, rows)
 st = R.kernel_stats()
-print(os.environ.get("AR_LIB", "default"), {k: round(1e3 * ms / n, 2) for k, (n, ms) in st.items() if n})
+print(os.path.basename(os.environ.get("AR_LIB", "default")), res, {k: round(1e3 * ms / n, 2) for k, (n, ms) in st.items() if n}, flush=True)
