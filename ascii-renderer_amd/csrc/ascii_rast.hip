@@ -54,7 +54,8 @@ struct FrameParams {
     int ramp_len, mode_on, mode_radius, mode_thresh;
     int want_ids;    // also store the winning (2*triangle + sub) per cell
     int ntx, nty;    // tile grid over columns [0, cols) x output rows [ya, yb)
-    int nbx, nby;    // bin grid (2x2 tiles per bin)
+    int nbx, nby;    // bin grid
+    int bshift;      // a bin is (1 << bshift)^2 tiles: 0 while the tiles fit the bin table, else 1
     uint32_t chunk, n_groups;  // triangles per k_setup workgroup, number of those workgroups
     uint32_t frame;  // frame counter (selects the binning state block)
     uint8_t ramp[AR_MAX_RAMP];
@@ -467,15 +468,14 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__re
 // that buffer in.
 // ------------------------------------------------------------------------------------------------
 constexpr int kTileW = 64, kTileH = 32, kTileCells = kTileW * kTileH;
-constexpr int kBinShift = 1;          // a bin is 2x2 tiles = 128x64 cells
-constexpr int kBinSide = 1 << kBinShift;
 constexpr int kMaxTiles = 8000;       // tiles per frame the tiled path accepts
 constexpr int kMaxBins = 2048;        // >= kMaxTiles / 4 for any tile-grid shape the path accepts
 constexpr int kSetupThreads = 256;    // k_setup / k_fill workgroup size
-constexpr uint32_t kMaxGroups = 4096;  // k_setup workgroups (rows of the count table)
+constexpr uint32_t kMaxGroups = 1024;  // k_setup workgroups (rows of the count table)
 constexpr int kTileBigMax = 512;      // per-tile list of records swept cooperatively
 constexpr int kTileSmallCells = 64;   // cell-range area (inside the tile) one lane scans itself
 constexpr int kTileListMax = 2048;    // ids staged in LDS between the filter and the raster step
+constexpr int kFilterBatch = 4;       // bin entries a k_tile lane loads per filter step
 constexpr uint32_t kFlagClipped = 1u; // record produced by the near-plane clip (vertices differ from the mesh's)
 constexpr uint32_t kFlagFlat = 2u;    // the triangle's three vertices carry identical normal and colour
 
@@ -568,8 +568,8 @@ __device__ __forceinline__ Vert<0> transform_position(const FrameParams &fp, flo
 // Range of bins a cell range touches.
 __device__ __forceinline__ void bin_range(const FrameParams &fp, int i0, int i1, int j0, int j1, int &bx0, int &bx1,
                                           int &by0, int &by1) {
-    bx0 = i0 >> (6 + kBinShift); bx1 = i1 >> (6 + kBinShift);
-    by0 = (fp.rows - 1 - j1 - fp.ya) >> (5 + kBinShift); by1 = (fp.rows - 1 - j0 - fp.ya) >> (5 + kBinShift);
+    bx0 = i0 >> (6 + fp.bshift); bx1 = i1 >> (6 + fp.bshift);
+    by0 = (fp.rows - 1 - j1 - fp.ya) >> (5 + fp.bshift); by1 = (fp.rows - 1 - j0 - fp.ya) >> (5 + fp.bshift);
 }
 
 // One sub-triangle that survived setup: screen-space vertices and inclusive cell range.
@@ -778,12 +778,13 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Bi
             for (int bx = bx0; bx <= bx1; bx++) {
                 const int b = by * fp.nbx + bx;
                 if (!fits[b]) { direct = true; continue; }
-                // tiles of this bin inside the record's tile range -> bit mask, bit = ay * kBinSide + ax
-                const int ax0 = max(tx0 - kBinSide * bx, 0), ax1 = min(tx1 - kBinSide * bx, kBinSide - 1);
-                const int ay0 = max(ty0 - kBinSide * by, 0), ay1 = min(ty1 - kBinSide * by, kBinSide - 1);
+                // tiles of this bin inside the record's tile range -> bit mask, bit = ay * side + ax
+                const int side = 1 << fp.bshift;
+                const int ax0 = max(tx0 - side * bx, 0), ax1 = min(tx1 - side * bx, side - 1);
+                const int ay0 = max(ty0 - side * by, 0), ay1 = min(ty1 - side * by, side - 1);
                 const uint32_t rowbits = ((1u << (ax1 + 1)) - 1u) & ~((1u << ax0) - 1u);
                 uint32_t m = 0;
-                for (int ay = ay0; ay <= ay1; ay++) m |= rowbits << (kBinSide * ay);
+                for (int ay = ay0; ay <= ay1; ay++) m |= rowbits << (side * ay);
                 entries[size_t(base[b]) + atomicAdd(&cnt[b], 1u)] = (unsigned long long)loc | ((unsigned long long)m << 32);
             }
         if (direct) {  // a bin it touches has no room: resolve through the global key buffer
@@ -856,7 +857,14 @@ __device__ __forceinline__ void raster_range(const FrameParams &fp, const Edges 
                                              int r0, int r1, int tx0, int tr0, uint64_t *keys) {
     constexpr float kBand = 1.0f / 262144.0f;  // 2^-18
     const float a32[3] = {float(ed.a[0]), float(ed.a[1]), float(ed.a[2])};
-    const float inv_a[3] = {1.0f / a32[0], 1.0f / a32[1], 1.0f / a32[2]};
+    // (hardware reciprocal: 1 ulp, inside the error budget above)
+    const float inv_a[3] = {__builtin_amdgcn_rcpf(a32[0]), __builtin_amdgcn_rcpf(a32[1]), __builtin_amdgcn_rcpf(a32[2])};
+    // coverage is E_k >= thr_k with thr_k = 0 on edges that own their boundary and the smallest positive
+    // binary64 otherwise (E_k > 0): the same decision as edge_inside with one comparison per edge
+    double thr[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        thr[k] = (ed.a[k] > 0.0 || (ed.a[k] == 0.0 && ed.b[k] > 0.0)) ? 0.0 : 4.9406564584124654e-324;
     const float apx[3] = {fabsf(a32[0]) * float(i1 + 1), fabsf(a32[1]) * float(i1 + 1), fabsf(a32[2]) * float(i1 + 1)};
     const int w = i1 - i0 + 1;
     const int rows_per_chunk = max(1, 64 / w);
@@ -883,13 +891,22 @@ __device__ __forceinline__ void raster_range(const FrameParams &fp, const Edges 
             const unsigned long long run = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
             cand |= run << ((rr - rc) * w + (ilo - i0));
         }
-        while (cand) {
-            const int k = __ffsll((long long)cand) - 1;
-            cand &= cand - 1ull;
+        uint32_t clo = uint32_t(cand), chi = uint32_t(cand >> 32);
+        while (clo | chi) {
+            int k;
+            if (clo) { k = __ffs(int(clo)) - 1; clo &= clo - 1u; }
+            else { k = 31 + __ffs(int(chi)); chi &= chi - 1u; }
             const int dr = int((float(k) + 0.5f) * inv_w);  // k / w, exact for k < 64
             const int rr = rc + dr, i = i0 + (k - dr * w);
-            float f[3], zw;
-            if (cover(ed, i, fp.rows - 1 - rr, f, zw))
+            const double px = double(i) + 0.5, py = double(fp.rows - 1 - rr) + 0.5;
+            const double E0 = ed.a[0] * px + (ed.b[0] * py + ed.c[0]);
+            const double E1 = ed.a[1] * px + (ed.b[1] * py + ed.c[1]);
+            const double E2 = ed.a[2] * px + (ed.b[2] * py + ed.c[2]);
+            const float f0 = float(E0), f1 = float(E1), f2 = float(E2);
+            const float den = (f0 * ed.W[0] + f1 * ed.W[1]) + f2 * ed.W[2];
+            const float num = (f0 * ed.Z[0] + f1 * ed.Z[1]) + f2 * ed.Z[2];
+            const float zw = (num / den) * 0.5f + 0.5f;
+            if ((E0 >= thr[0]) & (E1 >= thr[1]) & (E2 >= thr[2]) & (zw >= 0.0f) & (zw < 1.0f))
                 atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
                           (unsigned long long)make_key(zw, key_low));
         }
@@ -914,8 +931,9 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
     const int tile_x = int(blockIdx.x) % fp.ntx, tile_y = int(blockIdx.x) / fp.ntx;
     const int tx0 = tile_x * kTileW, tr0 = fp.ya + tile_y * kTileH;                      // first column / output row
     const int tx1 = min(tx0 + kTileW, fp.cols) - 1, tr1 = min(tr0 + kTileH, fp.yb) - 1;  // last column / row
-    const int bin = (tile_y >> kBinShift) * fp.nbx + (tile_x >> kBinShift);
-    const uint32_t bit = 1u << ((tile_y & (kBinSide - 1)) * kBinSide + (tile_x & (kBinSide - 1)));
+    const int side = 1 << fp.bshift;
+    const int bin = (tile_y >> fp.bshift) * fp.nbx + (tile_x >> fp.bshift);
+    const uint32_t bit = 1u << ((tile_y & (side - 1)) * side + (tile_x & (side - 1)));
     const BinState &st = state[fp.frame & 1u];
     for (int c = int(tid); c < kTileCells; c += 256) keys[c] = kBackgroundKey;
     if (tid == 0) { n_list = 0; n_big = 0; n_cov = 0; }
@@ -927,16 +945,21 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
 
     // filter the bin's entries by this tile's mask bit into the LDS list; whenever the list could
     // overflow on the next step (or at the end) rasterise what it holds
-    for (uint32_t eb = e_begin; eb < e_end || eb == e_begin; eb += 256) {
-        const uint32_t e = eb + tid;
-        if (e < e_end) {
-            const unsigned long long ent = entries[e];
-            if (uint32_t(ent >> 32) & bit) list[atomicAdd(&n_list, 1u)] = uint32_t(ent);
+    // (kFilterBatch entries per lane and step, all loads in flight together: the step is one memory latency)
+    for (uint32_t eb = e_begin;; eb += 256 * kFilterBatch) {
+        unsigned long long ent[kFilterBatch];
+#pragma unroll
+        for (int q = 0; q < kFilterBatch; q++) {
+            const uint32_t e = eb + uint32_t(q) * 256u + tid;
+            ent[q] = e < e_end ? entries[e] : 0ull;  // mask 0 never matches
         }
+#pragma unroll
+        for (int q = 0; q < kFilterBatch; q++)
+            if (uint32_t(ent[q] >> 32) & bit) list[atomicAdd(&n_list, 1u)] = uint32_t(ent[q]);
         __syncthreads();
         const uint32_t nl = n_list;
-        const bool last = eb + 256 >= e_end;
-        if (nl + 256 > uint32_t(kTileListMax) || last) {
+        const bool last = eb + 256 * kFilterBatch >= e_end;
+        if (nl + 256 * kFilterBatch > uint32_t(kTileListMax) || last) {
             // records with a small cell range inside the tile: one lane each; others -> sweep list
             for (uint32_t r = tid; r < nl; r += 256) {
                 const uint32_t loc = list[r];
@@ -1366,8 +1389,9 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
     const unsigned cell_blocks = unsigned((strip_cells + 255) / 256);
     fp.ntx = (cols + kTileW - 1) / kTileW;
     fp.nty = (fp.yb - fp.ya + kTileH - 1) / kTileH;
-    fp.nbx = (fp.ntx + kBinSide - 1) / kBinSide;
-    fp.nby = (fp.nty + kBinSide - 1) / kBinSide;
+    fp.bshift = 1;  // per-tile bins (0) shorten k_tile's filter but cost as much again in the binning kernels
+    fp.nbx = (fp.ntx + (1 << fp.bshift) - 1) >> fp.bshift;
+    fp.nby = (fp.nty + (1 << fp.bshift) - 1) >> fp.bshift;
     const size_t nt = size_t(fp.ntx) * fp.nty;
     const size_t nbins = size_t(fp.nbx) * fp.nby;
     const bool tiled = ctx->path == 0 && nt <= size_t(kMaxTiles) && nbins <= size_t(kMaxBins) && cols <= 65535 &&

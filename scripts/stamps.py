@@ -1,4 +1,4 @@
-"""Diagnostic: per-phase wall-clock shares of k_tile from a -DAR_STAMPS build (AR_LIB)."""
+"""Phase durations inside k_tile from the stamps variant (AR_LIB=build_variants/stamps.so)."""
 import importlib, os, sys, ctypes
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -6,6 +6,7 @@ ar = importlib.import_module("ascii-renderer_amd")
 ar.binding.LIB_PATH = os.environ["AR_LIB"]
 sc = ar.scenes.random_scene(1000000, 1920, 1080)
 R = ar.Renderer(0)
+R.set_option("overlap", 0)
 ar.scenes.upload(R, sc)
 for _ in range(5): R.render_async(1920, 1080)
 R.sync()
@@ -16,11 +17,17 @@ L.ar_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert L.ar_debug_stamps(out.ctypes.data_as(ctypes.c_void_p), n) == 0
 st = out.reshape(1020, 8).astype(np.int64)
 t0 = st[:, 0].min()
-names = ["filter", "raster small", "sweep+reset", "compact", "shade", "output"]
-print("kernel span (first stamp0 -> last stamp6): %.1f us" % ((st[:, 6].max() - t0) / 100.0))
-print("stamp0 spread: %.1f us" % ((st[:, 0].max() - t0) / 100.0))
-for k in range(6):
+names = ["filter", "raster small", "raster big", "compact", "shade", "output"]
+for k, nm in enumerate(names):
     d = (st[:, k + 1] - st[:, k]) / 100.0
-    print("%-14s mean %6.2f us  p95 %6.2f  max %6.2f" % (names[k], d.mean(), np.percentile(d, 95), d.max()))
+    print("%-12s mean %6.2f us p50 %6.2f p95 %6.2f max %6.2f" % (nm, d.mean(), np.percentile(d, 50), np.percentile(d, 95), d.max()))
 tot = (st[:, 6] - st[:, 0]) / 100.0
-print("per-tile total mean %.2f p95 %.2f max %.2f" % (tot.mean(), np.percentile(tot, 95), tot.max()))
+print("tile total   mean %6.2f us p95 %6.2f max %6.2f;  start spread %.2f us; kernel span %.2f us" % (
+    tot.mean(), np.percentile(tot, 95), tot.max(), (st[:, 0].max() - t0) / 100.0, (st[:, 6].max() - t0) / 100.0))
+print("records per tile mean %.0f max %d" % (st[:, 7].mean(), st[:, 7].max()))
+rs = (st[:, 2] - st[:, 1]) / 100.0
+nrec = st[:, 7]
+for lo, hi in ((0, 448), (448, 480), (480, 512), (512, 544), (544, 1000)):
+    m = (nrec > lo) & (nrec <= hi)
+    if m.any():
+        print("records %4d..%4d: %4d tiles, raster small mean %.2f p95 %.2f, tile total mean %.2f" % (lo, hi, m.sum(), rs[m].mean(), np.percentile(rs[m], 95), tot[m].mean()))
