@@ -13,7 +13,8 @@ N_KERNELS = 11
 EXPORTS = [
     "ar_create", "ar_destroy", "ar_last_error", "ar_set_mesh", "ar_set_camera", "ar_set_lights",
     "ar_set_ascii", "ar_set_strip", "ar_set_id_output", "ar_render", "ar_render_async", "ar_sync", "ar_read",
-    "ar_device_buffer", "ar_stream", "ar_quantize", "ar_set_profiling", "ar_kernel_stats",
+    "ar_device_buffer", "ar_stream", "ar_stream_wait_frame", "ar_frame_wait_stream", "ar_set_stream",
+    "ar_set_ascii_target", "ar_quantize", "ar_set_profiling", "ar_kernel_stats",
     "ar_frame_counters", "ar_set_option",
 ]
 _lib = None
@@ -58,13 +59,17 @@ def load_library():
     L.ar_device_buffer.restype = vp
     L.ar_stream.argtypes = [vp]
     L.ar_stream.restype = vp
+    L.ar_set_stream.argtypes = [vp, vp]
+    L.ar_set_ascii_target.argtypes = [vp, vp, ctypes.c_int]
+    L.ar_stream_wait_frame.argtypes = [vp, vp]
+    L.ar_frame_wait_stream.argtypes = [vp, vp]
     L.ar_quantize.argtypes = [vp, _u8p, ctypes.c_int, ctypes.c_int, _u8p]
     L.ar_set_profiling.argtypes = [vp, ctypes.c_int]
     L.ar_kernel_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), _u32p, _fp]
     L.ar_frame_counters.argtypes = [vp, _u32p]
     L.ar_set_option.argtypes = [vp, ctypes.c_int, ctypes.c_longlong]
     for name in ("ar_set_id_output", "ar_set_mesh", "ar_set_camera", "ar_set_lights", "ar_set_ascii", "ar_set_strip", "ar_set_id_output", "ar_render",
-                 "ar_render_async", "ar_sync", "ar_read", "ar_quantize", "ar_set_profiling", "ar_kernel_stats",
+                 "ar_render_async", "ar_sync", "ar_read", "ar_quantize", "ar_stream_wait_frame", "ar_frame_wait_stream", "ar_set_stream", "ar_set_ascii_target", "ar_set_profiling", "ar_kernel_stats",
                  "ar_frame_counters", "ar_set_option"):
         getattr(L, name).restype = ctypes.c_int
     _lib = L
@@ -174,6 +179,22 @@ class Renderer:
 
     def device_buffer(self, which):
         return self._L.ar_device_buffer(self._h, {"rgba": 0, "depth": 1, "ascii": 2}[which])
+
+    def set_stream(self, hip_stream):
+        """Runs the following frames on the caller's stream (integer hipStream_t); 0 / None: own streams."""
+        self._check(self._L.ar_set_stream(self._h, ctypes.c_void_p(int(hip_stream or 0))))
+
+    def set_ascii_target(self, device_ptr, first_row=0):
+        """The following frames write ASCII row r at device_ptr + (r - first_row) * cols; None: own buffer."""
+        self._check(self._L.ar_set_ascii_target(self._h, ctypes.c_void_p(int(device_ptr or 0)), int(first_row)))
+
+    def stream_wait_frame(self, hip_stream):
+        """Work enqueued on hip_stream (an integer hipStream_t) from now on waits for the frames enqueued so far."""
+        self._check(self._L.ar_stream_wait_frame(self._h, ctypes.c_void_p(int(hip_stream))))
+
+    def frame_wait_stream(self, hip_stream):
+        """Frames enqueued from now on write their outputs only after the work now on hip_stream is done."""
+        self._check(self._L.ar_frame_wait_stream(self._h, ctypes.c_void_p(int(hip_stream))))
 
     def quantize(self, rgba, cols, rows):
         rgba = np.ascontiguousarray(np.asarray(rgba, dtype=np.uint8).reshape(-1))

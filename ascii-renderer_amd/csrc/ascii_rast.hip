@@ -1218,13 +1218,19 @@ thread_local char g_create_error[256] = "";
 
 struct ar_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;   // pixel stream: tile resolve, shading, ASCII, copies; every output completes here
+    hipStream_t stream = nullptr;   // pixel stream: tile resolve, shading, copies (own_stream, or the caller's: ar_set_stream)
+    hipStream_t own_stream = nullptr;
+    bool ext_stream = false;        // stream is the caller's: every kernel goes there, frames do not overlap
+    uint8_t *ascii_target = nullptr;  // caller's device buffer for the ASCII plane (ar_set_ascii_target), else d_ascii
+    int target_row = 0;               // frame row stored at ascii_target
     hipStream_t gstream = nullptr;  // geometry stream: setup and binning of the next frame run beside the pixel work
     hipEvent_t ev_fill[2] = {nullptr, nullptr};  // per buffer set: binning of the frame using it is complete
     hipEvent_t ev_tile[2] = {nullptr, nullptr};  // per buffer set: the tiles of the frame using it are resolved
     hipStream_t astream = nullptr;  // ASCII stream: smoothing of frame f beside the tile resolve of frame f+1
     hipEvent_t ev_ascii[2] = {nullptr, nullptr}; // per ramp-index plane: the smoothing pass that reads it is done
     bool overlap = true;            // false: everything on the pixel stream
+    hipEvent_t ev_out[2] = {nullptr, nullptr};  // outputs complete on the pixel / ASCII stream (ar_stream_wait_frame)
+    hipEvent_t ev_ext = nullptr;    // a caller's stream has consumed the outputs (ar_frame_wait_stream)
     float *d_vbo = nullptr;
     uint32_t *d_idx = nullptr;
     uint32_t n_verts = 0, n_tris = 0;
@@ -1316,6 +1322,7 @@ struct Stamper {  // brackets one launch with events when profiling is on
 };
 
 int sync_streams(ar_ctx *ctx) {
+    if (ctx->stream != ctx->own_stream) AR_HIP(ctx, hipStreamSynchronize(ctx->own_stream));
     AR_HIP(ctx, hipStreamSynchronize(ctx->gstream));
     AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     AR_HIP(ctx, hipStreamSynchronize(ctx->astream));
@@ -1397,6 +1404,8 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
     const bool tiled = ctx->path == 0 && nt <= size_t(kMaxTiles) && nbins <= size_t(kMaxBins) && cols <= 65535 &&
                        rows <= 65535 && ctx->d_tripos;
     const int set = int(ctx->frame & 1u);  // buffer set of this frame (tiled path)
+    const bool overlap = ctx->overlap && !ctx->ext_stream;
+    uint8_t *ascii_out = ctx->ascii_target ? ctx->ascii_target - ptrdiff_t(ctx->target_row) * cols : ctx->d_ascii;
     if (tiled != ctx->last_tiled && ctx->rendered) {
         // the two paths share the key buffers and do not order themselves against each other's streams
         rc = sync_streams(ctx);
@@ -1463,10 +1472,10 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
     if (tiled) {
         // Binning of frame f runs on the geometry stream and may overlap the pixel work of frame f-1;
         // it only has to wait until the tiles of frame f-2 (the last user of this buffer set) are done.
-        hipStream_t gs = ctx->overlap ? ctx->gstream : ctx->stream;
+        hipStream_t gs = overlap ? ctx->gstream : ctx->stream;
         uint32_t *dircount = ctx->d_dircount[set];
         uint32_t *blocksum = dircount + ctx->dircount_cap, *boff = blocksum + 16 * size_t(kMaxBins);
-        if (ctx->overlap) AR_HIP(ctx, hipStreamWaitEvent(gs, ctx->ev_tile[set], 0));
+        if (overlap) AR_HIP(ctx, hipStreamWaitEvent(gs, ctx->ev_tile[set], 0));
         {
             Stamper s(ctx, K_SETUP, gs);
             k_setup<<<fp.n_groups, kSetupThreads, 0, gs>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_flat, ctx->d_records[set],
@@ -1485,7 +1494,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
             k_fill<<<fp.n_groups, kSetupThreads, 0, gs>>>(fp, ctx->d_records[set], ctx->d_surv[set], ctx->d_surv_count[set], dircount, boff,
                                                         ctx->d_state, ctx->d_entries[set], ctx->pool_cap, ctx->d_vis[set]);
         }
-        if (ctx->overlap) {
+        if (overlap) {
             AR_HIP(ctx, hipEventRecord(ctx->ev_fill[set], gs));
             AR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fill[set], 0));
             AR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_ascii[set], 0));  // ridx[set] was read by frame f-2's smoothing
@@ -1496,10 +1505,10 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
             Stamper s(ctx, K_TILE);
             k_tile<<<unsigned(nt), 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_tripos, ctx->tripos_stride,
                                                          ctx->d_records[set], ctx->d_entries[set], ctx->pool_cap, ctx->d_state,
-                                                         ctx->d_vis[set], ctx->d_rgba, ctx->d_depth, ctx->d_ascii, ctx->d_ridx[set],
+                                                         ctx->d_vis[set], ctx->d_rgba, ctx->d_depth, ascii_out, ctx->d_ridx[set],
                                                          ctx->d_ids);
         }
-        if (ctx->overlap) AR_HIP(ctx, hipEventRecord(ctx->ev_tile[set], ctx->stream));
+        if (overlap) AR_HIP(ctx, hipEventRecord(ctx->ev_tile[set], ctx->stream));
         ctx->frame++;
     } else {
         {
@@ -1519,20 +1528,20 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
         {
             Stamper s(ctx, K_SHADE);
             k_shade<<<cell_blocks, 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_vis[0], ctx->d_rgba, ctx->d_depth,
-                                                         ctx->d_ascii, ctx->d_ridx[0], ctx->d_ids, ctx->d_counters);
+                                                         ascii_out, ctx->d_ridx[0], ctx->d_ids, ctx->d_counters);
         }
     }
     if (fp.mode_on == 1) {
-        if (tiled && ctx->overlap) {
+        if (tiled && overlap) {
             AR_HIP(ctx, hipStreamWaitEvent(ctx->astream, ctx->ev_tile[set], 0));
             {
                 Stamper s(ctx, K_ASCII, ctx->astream);
-                launch_ascii<false>(fp, ctx->d_ridx[set], ctx->d_ascii, ctx->astream);
+                launch_ascii<false>(fp, ctx->d_ridx[set], ascii_out, ctx->astream);
             }
             AR_HIP(ctx, hipEventRecord(ctx->ev_ascii[set], ctx->astream));
         } else {
             Stamper s(ctx, K_ASCII);
-            launch_ascii<false>(fp, ctx->d_ridx[tiled ? set : 0], ctx->d_ascii, ctx->stream);
+            launch_ascii<false>(fp, ctx->d_ridx[tiled ? set : 0], ascii_out, ctx->stream);
         }
     }
     AR_HIP(ctx, hipGetLastError());
@@ -1554,9 +1563,13 @@ ar_ctx *ar_create(int device_id) {
     ar_ctx *ctx = new (std::nothrow) ar_ctx();
     if (!ctx) { fail(nullptr, AR_E_NOMEM, "out of host memory"); return nullptr; }
     ctx->device = device_id;
-    bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+    bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) == hipSuccess &&
+              (ctx->stream = ctx->own_stream) != nullptr &&
               hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&ctx->astream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_out[0], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_out[1], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&ctx->ev_ext, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&ctx->ev_ascii[0], hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&ctx->ev_ascii[1], hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&ctx->ev_fill[0], hipEventDisableTiming) == hipSuccess &&
@@ -1604,10 +1617,12 @@ void ar_destroy(ar_ctx *ctx) {
         if (ctx->ev_fill[k]) (void)hipEventDestroy(ctx->ev_fill[k]);
         if (ctx->ev_tile[k]) (void)hipEventDestroy(ctx->ev_tile[k]);
         if (ctx->ev_ascii[k]) (void)hipEventDestroy(ctx->ev_ascii[k]);
+        if (ctx->ev_out[k]) (void)hipEventDestroy(ctx->ev_out[k]);
     }
+    if (ctx->ev_ext) (void)hipEventDestroy(ctx->ev_ext);
     if (ctx->gstream) (void)hipStreamDestroy(ctx->gstream);
     if (ctx->astream) (void)hipStreamDestroy(ctx->astream);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
@@ -1735,6 +1750,45 @@ void *ar_device_buffer(ar_ctx *ctx, int which) {
 }
 
 void *ar_stream(ar_ctx *ctx) { return ctx ? ctx->stream : nullptr; }
+
+int ar_set_stream(ar_ctx *ctx, void *hip_stream) {
+    if (!ctx) return AR_E_ARG;
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = sync_streams(ctx);
+    if (rc) return rc;
+    ctx->ext_stream = hip_stream != nullptr;
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return 0;
+}
+
+int ar_set_ascii_target(ar_ctx *ctx, void *d_ascii, int first_row) {
+    if (!ctx) return AR_E_ARG;
+    if (first_row < 0) return fail(ctx, AR_E_ARG, "ar_set_ascii_target: bad first row %d", first_row);
+    ctx->ascii_target = static_cast<uint8_t *>(d_ascii);
+    ctx->target_row = d_ascii ? first_row : 0;
+    return 0;
+}
+
+int ar_stream_wait_frame(ar_ctx *ctx, void *hip_stream) {
+    if (!ctx) return AR_E_ARG;
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    AR_HIP(ctx, hipEventRecord(ctx->ev_out[0], ctx->stream));
+    AR_HIP(ctx, hipEventRecord(ctx->ev_out[1], ctx->astream));
+    AR_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_out[0], 0));
+    AR_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_out[1], 0));
+    return 0;
+}
+
+int ar_frame_wait_stream(ar_ctx *ctx, void *hip_stream) {
+    if (!ctx) return AR_E_ARG;
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    AR_HIP(ctx, hipEventRecord(ctx->ev_ext, static_cast<hipStream_t>(hip_stream)));
+    // the output buffers are written on the pixel stream (tiles) and the ASCII stream (smoothing)
+    AR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_ext, 0));
+    AR_HIP(ctx, hipStreamWaitEvent(ctx->astream, ctx->ev_ext, 0));
+    return 0;
+}
 
 int ar_quantize(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *ascii) {
     if (!ctx) return AR_E_ARG;

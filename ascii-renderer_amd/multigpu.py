@@ -40,3 +40,49 @@ def all_gather_strips(local_strip, out=None):
         out = torch.empty((h * world, cols), dtype=local_strip.dtype, device=local_strip.device)
     dist.all_gather_into_tensor(out.view(-1), local_strip.contiguous().view(-1))
     return out
+
+
+class StripBatcher:
+    """Collects this rank's ASCII band of `batch` consecutive frames in a ring and combines the bands of
+    all ranks with ONE all-gather per batch: a collective costs the host tens of microseconds, a frame
+    takes less, so gathering frame by frame would leave the GPUs waiting for the host.  Frame k of the
+    last gathered batch is frame(k) (every rank holds every full frame).
+
+    `device` tensors live wherever the bands live (HBM with RCCL, host memory with gloo in the tests)."""
+
+    def __init__(self, band_rows, cols, batch, device):
+        self.world = dist.get_world_size()
+        self.batch, self.h, self.cols = int(batch), int(band_rows), int(cols)
+        self.ring = torch.empty((self.batch, self.h, self.cols), dtype=torch.uint8, device=device)
+        self.out = torch.empty((self.world, self.batch, self.h, self.cols), dtype=torch.uint8, device=device)
+        self.filled = 0
+        self.gathered = 0      # frames held by `out`
+
+    def push(self, band):
+        """Copies one frame's band into the ring (stream-ordered on the current stream); gathers when full."""
+        self.ring[self.filled].copy_(band)
+        self.filled += 1
+        if self.filled == self.batch:
+            self.flush()
+
+    def slot_ptr(self):
+        """Device address of the ring slot the next frame's band belongs in (for ar_set_ascii_target)."""
+        return self.ring.data_ptr() + self.filled * self.h * self.cols
+
+    def advance(self):
+        """The renderer has been told to write the band into slot_ptr() itself (no copy); gathers when full."""
+        self.filled += 1
+        if self.filled == self.batch:
+            self.flush()
+
+    def flush(self):
+        if self.filled == 0:
+            return
+        dist.all_gather_into_tensor(self.out.view(-1), self.ring.view(-1))
+        self.gathered, self.filled = self.filled, 0
+
+    def frame(self, k):
+        """Full grid [world * band_rows, cols] of frame k of the last gathered batch."""
+        if not 0 <= k < self.gathered:
+            raise IndexError("frame %d of a batch of %d" % (k, self.gathered))
+        return self.out[:, k].reshape(self.world * self.h, self.cols)

@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--cols", type=int, default=COLS)
     ap.add_argument("--rows", type=int, default=ROWS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-batch", type=int, default=16, help="frames per RCCL all-gather (multi-GPU runs)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="take the strip + all-gather path even with one rank (rehearsal of the multi-GPU loop on one GPU)")
     args = ap.parse_args()
 
     import numpy as np
@@ -66,32 +69,44 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    gather = world > 1 or args.force_gather
+    if gather:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     mg = importlib.import_module("ascii-renderer_amd.multigpu")
     sc = ar.scenes.random_scene(args.tris, args.cols, args.rows)
     R = ar.Renderer(local_rank)
     ar.scenes.upload(R, sc)
     row0, row1 = mg.strip_bounds(args.rows, world, rank)
-    if world > 1:
+    if gather:
         R.set_strip(row0, row1)
-        gathered = torch.empty((args.rows, args.cols), dtype=torch.uint8, device="cuda")
+        batcher = mg.StripBatcher(row1 - row0, args.cols, max(1, args.gather_batch), "cuda")
     R.render_async(args.cols, args.rows)
     R.sync()
-    if world > 1:
-        local = mg.device_strip_tensor(R, args.cols, args.rows, row0, row1)
+    if gather:
+        # Everything of a rank goes on torch's current stream, which RCCL orders itself against: the
+        # renderer's kernels write the strip straight into a slot of the batch ring, and every
+        # --gather-batch frames one all-gather combines the ranks' rings.  No host waits, no cross-stream
+        # events (each costs the host several microseconds, as much as a kernel launch).
+        torch.cuda.set_stream(torch.cuda.Stream())         # a real stream handle (the default stream's is 0)
+        R.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def step():
-        R.render_async(args.cols, args.rows)
-        if world > 1:
-            R.sync()                                   # the strip must be complete before RCCL reads it
-            mg.all_gather_strips(local, gathered)
+        if not gather:
+            R.render_async(args.cols, args.rows)
+        else:
+            R.set_ascii_target(batcher.slot_ptr(), row0)
+            R.render_async(args.cols, args.rows)
+            batcher.advance()
 
     def fence():
+        if gather:
+            batcher.flush()
         R.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if gather:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -157,7 +172,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "random mesh mulberry32(0xA5C11), %d tris, %dx%d cells, camera at origin, default lights, "
                                    "modal smoothing on" % (args.tris, args.cols, args.rows),
-                       "partition": "1 GPU" if world == 1 else "%d row strips + RCCL all-gather of ASCII" % world,
+                       "partition": "1 GPU" if not gather else "%d row strips, RCCL all-gather of the ASCII strips every %d frames" % (world, max(1, args.gather_batch)),
                        "algorithmic_bytes_per_frame": ar.scenes.algorithmic_bytes(args.tris, args.cols, args.rows),
                        "frame_hbm_frac": ar.scenes.algorithmic_bytes(args.tris, args.cols, args.rows) * fps / 1e9 / HBM_PEAK_GBPS,
                        "queued_records": counters},
@@ -169,8 +184,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ar, sc)
         print(json.dumps(line), flush=True)
+    if gather:
+        # the gathered grid of the last frame must be the full frame: compare with this rank's own full render
+        torch.cuda.synchronize()
+        R.set_strip(0, 0)
+        R.set_ascii_target(None)
+        full = torch.from_numpy(R.render(args.cols, args.rows)["ascii"]).cuda()
+        if not torch.equal(full, batcher.frame(batcher.gathered - 1)):
+            raise SystemExit("rank %d: gathered ASCII grid differs from a full-frame render" % rank)
     R.close()
-    if world > 1:
+    if gather:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -86,8 +86,32 @@ int ar_read(ar_ctx *ctx, uint8_t *rgba, float *depth, uint8_t *ascii, uint32_t *
  * is destroyed): which = 0 rgba, 1 depth, 2 ascii.  NULL before the first render. */
 void *ar_device_buffer(ar_ctx *ctx, int which);
 
-/* The HIP stream (hipStream_t) the context launches on. */
+/* The HIP stream (hipStream_t) on which RGBA and depth complete.  A frame uses further streams of the
+ * context (see AR_OPT_OVERLAP); to order other work against a frame use ar_sync or the two calls below. */
 void *ar_stream(ar_ctx *ctx);
+
+/* Runs every kernel of the following frames on the caller's stream (hipStream_t of the context's device)
+ * instead of the context's own streams: frames are then ordered with the caller's other work on that
+ * stream (an RCCL collective, a copy) by the stream itself, at the price of frames no longer overlapping.
+ * NULL returns to the context's own streams.  No counterpart in the reference. */
+int ar_set_stream(ar_ctx *ctx, void *hip_stream);
+
+/* Lets the following frames store the ASCII plane in the caller's device buffer instead of the
+ * context's: frame row r is written at d_ascii + (r - first_row) * cols, only for the rows of the
+ * current strip, so a strip can be written densely into a slot of a larger gather buffer.  While a
+ * target is set, ar_read / ar_render return the ASCII plane of the last frame rendered without one.
+ * NULL returns to the context's own buffer.  No counterpart in the reference. */
+int ar_set_ascii_target(ar_ctx *ctx, void *d_ascii, int first_row);
+
+/* Stream-ordered hand-over of the outputs, without blocking the host (no counterpart in the reference;
+ * used to feed the ASCII strips to RCCL):
+ *   ar_stream_wait_frame  work enqueued on hip_stream after this call starts only when every output of
+ *                         the frames enqueued so far is complete;
+ *   ar_frame_wait_stream  frames enqueued after this call write the output buffers only when the work
+ *                         enqueued on hip_stream so far is complete.
+ * hip_stream is a hipStream_t of the context's device. */
+int ar_stream_wait_frame(ar_ctx *ctx, void *hip_stream);
+int ar_frame_wait_stream(ar_ctx *ctx, void *hip_stream);
 
 /* RGBA8 grid -> ASCII codes with the context's ASCII parameters; alpha 2..254 is a literal code.
  * Replaces: AsciiPass.drawFromBuffer = blit + draw, index half (ascii_pass.js:238-302) and its CPU

@@ -38,6 +38,16 @@ def _worker(rank, world, port, tmp):
     local = torch.from_numpy(full[row0:row1].copy())          # this rank's band only
     got = mg.all_gather_strips(local)
     ok = np.array_equal(got.numpy(), full)
+    # batched variant: three different frames (rolled copies of the grid), one collective per two frames
+    frames = [np.roll(full, 7 * k, axis=1) for k in range(3)]
+    sb = mg.StripBatcher(row1 - row0, cols, 2, "cpu")
+    sb.push(torch.from_numpy(frames[0][row0:row1].copy()))
+    ok = ok and sb.gathered == 0
+    sb.push(torch.from_numpy(frames[1][row0:row1].copy()))
+    ok = ok and sb.gathered == 2 and np.array_equal(sb.frame(0).numpy(), frames[0]) and np.array_equal(sb.frame(1).numpy(), frames[1])
+    sb.push(torch.from_numpy(frames[2][row0:row1].copy()))
+    sb.flush()
+    ok = ok and sb.gathered == 1 and np.array_equal(sb.frame(0).numpy(), frames[2])
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
