@@ -1228,7 +1228,7 @@ struct ar_ctx {
     hipEvent_t ev_tile[2] = {nullptr, nullptr};  // per buffer set: the tiles of the frame using it are resolved
     hipStream_t astream = nullptr;  // ASCII stream: smoothing of frame f beside the tile resolve of frame f+1
     hipEvent_t ev_ascii[2] = {nullptr, nullptr}; // per ramp-index plane: the smoothing pass that reads it is done
-    bool overlap = true;            // false: everything on the pixel stream
+    int overlap = 2;                // 0: everything on the pixel stream, 1: frames overlap on three streams, 2: decide per frame
     hipEvent_t ev_out[2] = {nullptr, nullptr};  // outputs complete on the pixel / ASCII stream (ar_stream_wait_frame)
     hipEvent_t ev_ext = nullptr;    // a caller's stream has consumed the outputs (ar_frame_wait_stream)
     float *d_vbo = nullptr;
@@ -1404,7 +1404,9 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
     const bool tiled = ctx->path == 0 && nt <= size_t(kMaxTiles) && nbins <= size_t(kMaxBins) && cols <= 65535 &&
                        rows <= 65535 && ctx->d_tripos;
     const int set = int(ctx->frame & 1u);  // buffer set of this frame (tiled path)
-    const bool overlap = ctx->overlap && !ctx->ext_stream;
+    // the cross-stream events of an overlapped frame cost the host about as much as 40 us of GPU time:
+    // below that much work per frame the single-stream schedule is the faster one
+    const bool overlap = !ctx->ext_stream && (ctx->overlap == 1 || (ctx->overlap == 2 && ctx->n_tris >= 100000u));
     uint8_t *ascii_out = ctx->ascii_target ? ctx->ascii_target - ptrdiff_t(ctx->target_row) * cols : ctx->d_ascii;
     if (tiled != ctx->last_tiled && ctx->rendered) {
         // the two paths share the key buffers and do not order themselves against each other's streams
@@ -1879,10 +1881,10 @@ int ar_set_option(ar_ctx *ctx, int option, long long value) {
             ctx->path = int(value);
             return 0;
         case AR_OPT_OVERLAP: {
-            if (value != 0 && value != 1) return fail(ctx, AR_E_ARG, "AR_OPT_OVERLAP takes 0 or 1");
+            if (value < 0 || value > 2) return fail(ctx, AR_E_ARG, "AR_OPT_OVERLAP takes 0, 1 or 2");
             int rc = sync_streams(ctx);
             if (rc) return rc;
-            ctx->overlap = value != 0;
+            ctx->overlap = int(value);
             return 0;
         }
         case AR_OPT_POOL_RECORDS:

@@ -136,7 +136,7 @@ def main():
     for _ in range(args.steps):
         R.render_async(args.cols, args.rows)
     stats_serial = R.kernel_stats()
-    R.set_option("overlap", 1)
+    R.set_option("overlap", 2)
     R.set_profiling(False)
     counters = R.frame_counters()
 

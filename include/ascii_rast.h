@@ -135,9 +135,11 @@ int ar_frame_counters(ar_ctx *ctx, uint32_t out[8]);
  *   AR_OPT_PATH          0 (default): tile-binned path whenever the grid has at most 8000 tiles of
  *                        64x32 cells, else the direct path; 1: always the direct path (every
  *                        fragment resolved with a 64-bit atomic min in HBM).
- *   AR_OPT_OVERLAP       1 (default): the tiled path runs triangle setup and binning of a frame on a second
- *                        stream, so that consecutive ar_render_async frames overlap (setup of frame f+1 beside
- *                        the tile resolve of frame f); 0: one stream, frames strictly one after the other.
+ *   AR_OPT_OVERLAP       1: the tiled path spreads a frame over three streams (setup + binning, tile resolve,
+ *                        ASCII smoothing) so that consecutive ar_render_async frames overlap; 0: one stream,
+ *                        frames strictly one after the other; 2 (default): 1 for meshes of at least 100000
+ *                        triangles, else 0 (the cross-stream events cost the host more than they gain on
+ *                        small frames).
  *   AR_OPT_POOL_RECORDS  capacity of the tiled path's (sub-triangle, bin) entry pool in entries;
  *                        0 (default) sizes it as 2 x triangles + 65536. */
 #define AR_OPT_PATH 1

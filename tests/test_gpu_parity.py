@@ -187,6 +187,61 @@ def test_back_to_back_frames_overlap_without_interfering(pkg, oracle):
         r.close()
 
 
+def test_callers_stream_ascii_target_and_stream_handover(pkg, oracle):
+    """The calls the multi-GPU loop is built from: frames on the caller's stream writing their ASCII strip
+    into the caller's buffer (ar_set_stream, ar_set_ascii_target), and the stream-ordered hand-over
+    between the context's own streams and a caller's stream (ar_stream_wait_frame / ar_frame_wait_stream)."""
+    import importlib
+    import torch
+    mg = importlib.import_module("ascii-renderer_amd.multigpu")
+    r = pkg.Renderer(0)
+    try:
+        cols, rows = 640, 360
+        sc = pkg.scenes.random_scene(150_000, cols, rows, mesh_grid=(cols, rows))
+        pkg.scenes.upload(r, sc)
+        cams = [{"pos": (0.0, 0.0, 0.0), "yaw": 0.03 * k, "pitch": -0.02 * k} for k in range(3)]
+        want = []
+        for cam in cams:
+            proj, view = pkg.host.camera_matrices(cam, cols, rows, 1.0)
+            rgba, _d, _i = oracle.render(sc["vbo"], sc["idx"], proj, view, sc["lights"], cols, rows)
+            want.append((proj, view, oracle.quantize(rgba, cols, rows, pkg.scenes.DEFAULT_RAMP, 1, 2, 12)))
+        st = torch.cuda.Stream()
+        # (1) caller's stream + ASCII target: three strips of three different frames, densely into a ring
+        row0, row1 = 120, 240
+        ring = torch.zeros((3, row1 - row0, cols), dtype=torch.uint8, device="cuda")
+        r.set_stream(st.cuda_stream)
+        r.set_strip(row0, row1)
+        for k in range(3):
+            r.set_camera(want[k][0], want[k][1])
+            r.set_ascii_target(ring[k].data_ptr(), row0)
+            r.render_async(cols, rows)
+        st.synchronize()
+        for k in range(3):
+            assert np.array_equal(ring[k].cpu().numpy(), want[k][2][row0:row1]), "ring slot %d" % k
+        r.set_stream(None)
+        r.set_ascii_target(None)
+        r.set_strip(0, 0)
+        # (2) own streams, hand-over to the caller's stream and back
+        r.set_camera(want[0][0], want[0][1])
+        r.render_async(cols, rows)
+        r.sync()
+        local = mg.device_strip_tensor(r, cols, rows, 0, rows)
+        r.set_camera(want[1][0], want[1][1])
+        r.render_async(cols, rows)
+        r.stream_wait_frame(st.cuda_stream)
+        with torch.cuda.stream(st):
+            snap = local.clone()
+        r.frame_wait_stream(st.cuda_stream)
+        r.set_camera(want[2][0], want[2][1])
+        r.render_async(cols, rows)
+        out = r.read()
+        st.synchronize()
+        assert np.array_equal(snap.cpu().numpy(), want[1][2])
+        assert np.array_equal(out["ascii"], want[2][2])
+    finally:
+        r.close()
+
+
 def test_many_tiles_take_the_direct_path(pkg, oracle):
     """More than 8000 tiles (here 8192 x 2048 cells = 8192 tiles): the library falls back to the direct path."""
     r = pkg.Renderer(0)
