@@ -25,6 +25,6 @@ res = {"_note": "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; _raw h
        "_raw": {k: {"FETCH_SIZE": fetch.get(k), "WRITE_SIZE": write.get(k)} for k in sorted(set(fetch) | set(write))}}
 for k in sorted(set(fetch) | set(write)):
     if k.startswith("k_"):
-        res[k] = int((2.0 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024)
+        res["k_ascii" if k.startswith("k_ascii") else k] = int((2.0 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024)
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k.startswith("k_")}))
