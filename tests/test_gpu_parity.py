@@ -351,3 +351,16 @@ def test_quantize_modal_vs_oracle(pkg, oracle, R):
         got = R.quantize(rgba, cols, rows)
         want = oracle.quantize(rgba, cols, rows, "@%#*+=-:. ", 1, radius, thresh)
         assert np.array_equal(got, want), (cols, rows)
+
+
+def test_randomised_sweep_against_oracle():
+    """250 random small scenes (soups with duplicates and screen-filling triangles, smooth meshes, poisoned
+    input; random cameras, grids, lights, ramps, smoothing, strips, paths, pool sizes, stream schedules):
+    scripts/fuzz_parity.py exits non-zero on the first run with any mismatch."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_parity.py"), "250", "42"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "250 cases, 0 mismatches" in r.stdout
