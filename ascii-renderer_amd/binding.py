@@ -13,7 +13,7 @@ N_KERNELS = 11
 EXPORTS = [
     "ar_create", "ar_destroy", "ar_last_error", "ar_set_mesh", "ar_set_camera", "ar_set_lights",
     "ar_set_ascii", "ar_set_strip", "ar_set_id_output", "ar_render", "ar_render_async", "ar_sync", "ar_read",
-    "ar_device_buffer", "ar_stream", "ar_stream_wait_frame", "ar_frame_wait_stream", "ar_set_stream",
+    "ar_device_buffer", "ar_stream", "ar_host_alloc", "ar_host_free", "ar_stream_wait_frame", "ar_frame_wait_stream", "ar_set_stream",
     "ar_set_ascii_target", "ar_quantize", "ar_set_profiling", "ar_kernel_stats",
     "ar_frame_counters", "ar_set_option",
 ]
@@ -59,6 +59,10 @@ def load_library():
     L.ar_device_buffer.restype = vp
     L.ar_stream.argtypes = [vp]
     L.ar_stream.restype = vp
+    L.ar_host_alloc.argtypes = [vp, ctypes.c_size_t]
+    L.ar_host_alloc.restype = vp
+    L.ar_host_free.argtypes = [vp]
+    L.ar_host_free.restype = None
     L.ar_set_stream.argtypes = [vp, vp]
     L.ar_set_ascii_target.argtypes = [vp, vp, ctypes.c_int]
     L.ar_stream_wait_frame.argtypes = [vp, vp]
@@ -179,6 +183,20 @@ class Renderer:
 
     def device_buffer(self, which):
         return self._L.ar_device_buffer(self._h, {"rgba": 0, "depth": 1, "ascii": 2}[which])
+
+    def host_array(self, shape, dtype):
+        """numpy array over page-locked host memory (ar_host_alloc): device->host copies into it run at
+        the full PCIe rate.  The memory is released when the array (and its views) are gone."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        p = self._L.ar_host_alloc(self._h, n)
+        if not p:
+            raise AsciiRastError((self._L.ar_last_error(self._h) or b"").decode())
+        buf = (ctypes.c_uint8 * max(n, 1)).from_address(p)
+        arr = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+        import weakref
+        weakref.finalize(buf, self._L.ar_host_free, p)
+        return arr
 
     def set_stream(self, hip_stream):
         """Runs the following frames on the caller's stream (integer hipStream_t); 0 / None: own streams."""

@@ -1,17 +1,21 @@
 // ascii_rast.hip - MI355X (gfx950) 3D -> ASCII rasterizer: HIP kernels and the C ABI around them.
 //
-// Frame pipeline (all on one HIP stream, nothing leaves HBM between stages):
-//   k_clear          visibility buffer <- (depth 1.0, no triangle)
-//   k_raster         one lane per triangle: vertex transform, near clip, edge setup, cull, cell range;
-//                    small triangles are scanned in place, larger ones are queued as setup records
-//   k_raster_medium  one wavefront per queued record, 8x8 cells per step
-//   k_raster_large   one lane per cell scanning the (short) list of screen-filling records
-//   k_shade          one lane per cell: winner's varyings, Lambert + point lights, RGBA8, depth,
-//                    ramp quantisation (ASCII written here when smoothing is off)
-//   k_ascii          modal smoothing over the quantised grid -> ASCII codes
-// Visibility is resolved with one 64-bit key per cell, (depth bits << 32) | (2*triangle + sub),
-// reduced with unsigned min: smaller depth wins, equal depth goes to the earlier triangle, and the
-// result does not depend on the order in which lanes, waves or kernels reach a cell.
+// Two resolve paths produce identical frames (nothing leaves HBM between their stages):
+//   tiled (default)   k_setup -> k_binscan -> k_binoffsets -> k_fill -> k_tile -> k_ascii_plane
+//                     triangles are set up once, binned to screen bins and resolved per 64x32-cell
+//                     tile in LDS; described in front of k_tristream.
+//   direct            k_raster -> k_raster_medium -> k_raster_large -> k_shade -> k_ascii_plane
+//                     k_raster: one lane per triangle (vertex transform, near clip, edge setup, cull,
+//                     cell range); small triangles are scanned in place, larger ones queued as setup
+//                     records for k_raster_medium (one wavefront per record, 8x8 cells per step) and
+//                     k_raster_large (one lane per cell scanning the short list of screen-filling
+//                     records); k_shade: one lane per cell (winner's varyings, Lambert + point lights,
+//                     RGBA8, depth, ramp quantisation; ASCII written here when smoothing is off).
+//                     Used for grids beyond the tiled path's tile budget, or on request.
+// Visibility is resolved with one 64-bit key per cell, (depth bits << 32) | order, reduced with unsigned
+// min: smaller depth wins, equal depth goes to the earlier triangle (order = 2*triangle + sub on the
+// direct path, the record slot - handed out in triangle order - on the tiled path), and the result
+// does not depend on the order in which lanes, waves or kernels reach a cell.
 //
 // Arithmetic follows a fixed contract (binary32 transforms and shading, binary64 edge functions,
 // no fused multiply-add, correctly rounded division and square root) so that the output is
@@ -439,23 +443,24 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__re
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tiled path: sub-triangles are binned to screen bins of 2x2 tiles, each 64x32-cell tile is
-// resolved in LDS.
+// Tiled path: sub-triangles are binned to screen bins of 2x2 tiles, each 64x32-cell tile is resolved
+// in LDS.
 //
 //   k_tristream (at mesh upload) gathers, per triangle, the three positions into nine planes of
 //             n_tris floats (36 contiguous, coalesced bytes per triangle for the per-frame pass),
-//             the three vertices' varyings into one 108-byte row (one gather per shaded cell
-//             instead of index -> vertex chasing) and a flag telling whether the triangle is flat
-//             (identical normal and colour at its three vertices).
-//   k_setup   one pass over the positions, one lane per triangle slot: transform, near clip, cull,
-//             cell range.  Every sub-triangle that can produce fragments gets its 64-byte setup
-//             record at records[id] (id = 2*triangle + sub), its id appended to the workgroup's
-//             survivor list, and is counted into the workgroup's LDS histogram over bins, which is
-//             then published as one row of the count table.
-//   k_binscan column-wise exclusive prefix of the count table over the k_setup workgroups (in place)
-//             and the bin totals: every (workgroup, bin) pair gets a fixed slice of the bin's entry
-//             array without a single global atomic.
-//   k_binoffsets  bin totals, start of each bin's entry array (exclusive scan), row-block offsets.
+//             the three vertices' normals and colours into one 96-byte row (one gather per shaded
+//             cell instead of index -> vertex chasing) and a flag telling whether the triangle is
+//             flat (identical normal and colour at its three vertices).
+//   k_setup   one pass over the positions, one triangle per lane and pass: transform, near clip,
+//             cull, cell range.  Every sub-triangle that can produce fragments gets a 64-byte setup
+//             record in the workgroup's block of record slots (dense, in triangle order), a 16-byte
+//             tuple for k_fill, and is counted into the workgroup's LDS histogram over bins, which
+//             is then published as one row of the count table.
+//   k_binscan column-wise exclusive prefix of the count table over the k_setup workgroups (in
+//             place, two levels) and per-row-block bin totals: every (workgroup, bin) pair gets a
+//             fixed slice of the bin's entry array without a single global atomic.
+//   k_binoffsets  bin totals, start of each bin's entry array (exclusive scan), row-block offsets,
+//             overflow flag.
 //   k_fill    every k_setup workgroup's survivors become one entry (record slot, mask of the bin's
 //             tiles the cell range touches) per (survivor, bin), written into that workgroup's slice.
 //   k_tile    one workgroup per tile: filters its bin's entries by mask bit into an LDS work list,
@@ -464,8 +469,10 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__re
 //             the covered cells and writes the tile's RGBA / depth / ramp-index rows.  Visibility
 //             keys never touch HBM.
 // If the entry pool cannot hold a bin, the sub-triangles touching that bin are rasterised straight
-// into the global key buffer by k_fill, which raises the frame's overflow flag; k_tile then merges
+// into a global key buffer by k_fill, k_binoffsets raises the frame's overflow flag and k_tile merges
 // that buffer in.
+// Everything these kernels write exists twice (by frame parity), so that consecutive frames can
+// overlap: see enqueue_frame.
 // ------------------------------------------------------------------------------------------------
 constexpr int kTileW = 64, kTileH = 32, kTileCells = kTileW * kTileH;
 constexpr int kMaxTiles = 8000;       // tiles per frame the tiled path accepts
@@ -491,7 +498,7 @@ static_assert(sizeof(BinRec) == 64, "bin records are four 16-byte loads");
 // write, so that the binning of frame f+1 can run while frame f's tiles are still being resolved.
 struct BinState {
     uint32_t total[kMaxBins];
-    uint32_t start[kMaxBins];   // exclusive scan of total (written by k_fill's first workgroup)
+    uint32_t start[kMaxBins];   // exclusive scan of total (k_binoffsets)
     uint32_t overflow;          // some bin did not fit the entry pool
     uint32_t n_entries;         // sum of total
     uint32_t pad[2];
@@ -1648,7 +1655,7 @@ int ar_set_mesh(ar_ctx *ctx, const float *vbo9, uint32_t n_verts, const uint32_t
     AR_HIP(ctx, hipMalloc(&ctx->d_idx, size_t(n_tris) * 3 * sizeof(uint32_t)));
     AR_HIP(ctx, hipMemcpy(ctx->d_vbo, vbo9, size_t(n_verts) * 9 * sizeof(float), hipMemcpyHostToDevice));
     AR_HIP(ctx, hipMemcpy(ctx->d_idx, idx, size_t(n_tris) * 3 * sizeof(uint32_t), hipMemcpyHostToDevice));
-    // derived, position-only stream for the binning pass and the per-id record store of the tiled path
+    // derived streams of the tiled path (positions, attribute rows, flat flags) and its record slots
     ctx->tripos_stride = (size_t(n_tris) + 63) / 64 * 64;
     AR_HIP(ctx, hipMalloc(&ctx->d_tripos, 9 * ctx->tripos_stride * sizeof(float)));
     AR_HIP(ctx, hipMalloc(&ctx->d_triattr, size_t(n_tris) * 24 * sizeof(float)));
@@ -1752,6 +1759,20 @@ void *ar_device_buffer(ar_ctx *ctx, int which) {
 }
 
 void *ar_stream(ar_ctx *ctx) { return ctx ? ctx->stream : nullptr; }
+
+void *ar_host_alloc(ar_ctx *ctx, size_t bytes) {
+    if (!ctx) return nullptr;
+    void *p = nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        fail(ctx, AR_E_NOMEM, "ar_host_alloc: cannot allocate %zu bytes of page-locked host memory", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void ar_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
 
 int ar_set_stream(ar_ctx *ctx, void *hip_stream) {
     if (!ctx) return AR_E_ARG;

@@ -228,6 +228,31 @@ napi_value js_quantize(napi_env env, napi_callback_info info) {
     return nullptr;
 }
 
+void finalize_host(napi_env, void *data, void *) { ar_host_free(data); }
+
+// allocHost(handle, bytes) -> ArrayBuffer over page-locked host memory (freed when the buffer is collected)
+napi_value js_alloc_host(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    double bytes = 0;
+    if (napi_get_value_double(env, argv[1], &bytes) != napi_ok || !(bytes >= 0) || bytes > 1e12) {
+        napi_throw_range_error(env, nullptr, "allocHost: bad size");
+        return nullptr;
+    }
+    void *p = ar_host_alloc(ctx, size_t(bytes));
+    if (!p) return throw_ar(env, ctx, "ar_host_alloc");
+    memset(p, 0, size_t(bytes));
+    napi_value buf;
+    if (napi_create_external_arraybuffer(env, p, size_t(bytes), finalize_host, nullptr, &buf) != napi_ok) {
+        ar_host_free(p);
+        napi_throw_error(env, nullptr, "allocHost: cannot wrap the buffer");
+        return nullptr;
+    }
+    return buf;
+}
+
 napi_value js_frame_counters(napi_env env, napi_callback_info info) {
     napi_value argv[1];
     if (!get_args(env, info, 1, argv)) return nullptr;
@@ -258,6 +283,7 @@ napi_value init(napi_env env, napi_value exports) {
         {"render", nullptr, js_render, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"quantize", nullptr, js_quantize, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"frameCounters", nullptr, js_frame_counters, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"allocHost", nullptr, js_alloc_host, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     };
     napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
     return exports;

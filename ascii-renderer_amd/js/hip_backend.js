@@ -234,6 +234,18 @@ export class HipRasterBackend {
     this._width = 0; this._height = 0;
     this._lastTopDown = null;   // last frame, row 0 = top
     this._forceDirect = !!(opts && opts.directPath);
+    this._pinned = new WeakSet();  // framebuffers handed out by allocFramebuffer
+  }
+
+  // Uint8ClampedArray(cols*rows*4) over page-locked host memory.  render() fills such a framebuffer by
+  // DMA straight from the GPU (no staging copy, no second copy from the backend's own image); getPixels
+  // then serves from it, so it must not be overwritten before the next render if getPixels is used.
+  // Plain typed arrays (the reference's fbA / fbB, js/main.js:243-248) keep working as before.
+  allocFramebuffer(cols, rows) {
+    this._ensure();
+    const fb = new Uint8ClampedArray(native().allocHost(this._h, cols * rows * 4));
+    this._pinned.add(fb);
+    return fb;
   }
 
   _ensure() {
@@ -246,6 +258,7 @@ export class HipRasterBackend {
     if (this._h) native().destroy(this._h);
     this._h = null;
     this._lastTopDown = null;
+    this._own = null;
     this._hasGeometry = false;
   }
 
@@ -273,9 +286,15 @@ export class HipRasterBackend {
     N.setCamera(this._h, m.proj, m.view);
     N.setLights(this._h, L.ambient, L.dir, L.dirColor, L.plPos, L.plCol);
     N.setAscii(this._h, rampBytes(config.ASCII_RAMP || '@%#*+=-:. '), mode.on, mode.radius, mode.thresh);
-    if (!this._lastTopDown || this._lastTopDown.length !== w * h * 4) this._lastTopDown = new Uint8Array(w * h * 4);
     const depth = (appState && appState.depth && appState.depth.length === w * h) ? appState.depth : null;
     const ascii = (appState && appState.ascii && appState.ascii.length === w * h) ? appState.ascii : null;
+    if (framebuffer && framebuffer.length === w * h * 4 && this._pinned.has(framebuffer)) {
+      N.render(this._h, w, h, framebuffer, depth, ascii);
+      this._lastTopDown = framebuffer;
+      return;
+    }
+    if (!this._own || this._own.length !== w * h * 4) this._own = new Uint8Array(N.allocHost(this._h, w * h * 4));
+    this._lastTopDown = this._own;
     N.render(this._h, w, h, this._lastTopDown, depth, ascii);
     if (framebuffer && framebuffer.length === this._lastTopDown.length) framebuffer.set(this._lastTopDown);
   }

@@ -10,6 +10,7 @@
 #ifndef ASCII_RAST_H
 #define ASCII_RAST_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -89,6 +90,13 @@ void *ar_device_buffer(ar_ctx *ctx, int which);
 /* The HIP stream (hipStream_t) on which RGBA and depth complete.  A frame uses further streams of the
  * context (see AR_OPT_OVERLAP); to order other work against a frame use ar_sync or the two calls below. */
 void *ar_stream(ar_ctx *ctx);
+
+/* Page-locked host memory for output buffers.  ar_render / ar_read copy into any host pointer, but into
+ * ordinary pageable memory the copy is bounced through the runtime's staging buffers at about a third of
+ * the PCIe rate; a framebuffer from ar_host_alloc is written by DMA directly.  No counterpart in the
+ * reference (its framebuffers are plain typed arrays, js/main.js:243-248).  ar_host_free(NULL) is a no-op. */
+void *ar_host_alloc(ar_ctx *ctx, size_t bytes);
+void ar_host_free(void *p);
 
 /* Runs every kernel of the following frames on the caller's stream (hipStream_t of the context's device)
  * instead of the context's own streams: frames are then ordered with the caller's other work on that

@@ -68,6 +68,20 @@ const dump = (name, ta) => fs.writeFileSync(path.join(outDir, name), Buffer.from
   meta.row5 = pass.rowString(5).slice(10, 10 + text.length);
   pass.dispose();
 
+  // a framebuffer from the backend's page-locked allocator is filled directly and must hold the same frame
+  {
+    const { HipRasterBackend } = await import(path.join(JS, 'hip_backend.js'));
+    const direct = new HipRasterBackend();
+    direct.setScene(sceneApi.meshScene(ico, { lights }));
+    const pfb = direct.allocFramebuffer(640, 360);
+    if (!(pfb instanceof Uint8ClampedArray) || pfb.length !== 640 * 360 * 4) throw new Error('allocFramebuffer shape');
+    direct.render(0.0, pfb, { cols: 640, rows: 360 });
+    if (Buffer.compare(Buffer.from(pfb.buffer, pfb.byteOffset, pfb.length), Buffer.from(f2.fb.buffer)) !== 0) throw new Error('pinned framebuffer differs');
+    const back = direct.getPixels({});
+    if (back[0] !== pfb[(359 * 640) * 4]) throw new Error('getPixels after a pinned render');
+    direct.dispose();
+  }
+
   // empty scene: early return, buffers untouched (raster.js:274)
   router.setScene({});
   const untouched = new Uint8ClampedArray(80 * 40 * 4).fill(9);
