@@ -14,7 +14,7 @@ EXPORTS = [
     "ar_create", "ar_destroy", "ar_last_error", "ar_set_mesh", "ar_set_camera", "ar_set_lights",
     "ar_set_ascii", "ar_set_strip", "ar_set_id_output", "ar_render", "ar_render_async", "ar_sync", "ar_read",
     "ar_device_buffer", "ar_stream", "ar_host_alloc", "ar_host_free", "ar_stream_wait_frame", "ar_frame_wait_stream", "ar_set_stream",
-    "ar_set_ascii_target", "ar_quantize", "ar_set_profiling", "ar_kernel_stats",
+    "ar_set_ascii_target", "ar_quantize", "ar_quantize_colors", "ar_read_colors", "ar_set_profiling", "ar_kernel_stats",
     "ar_frame_counters", "ar_set_option",
 ]
 _lib = None
@@ -68,12 +68,14 @@ def load_library():
     L.ar_stream_wait_frame.argtypes = [vp, vp]
     L.ar_frame_wait_stream.argtypes = [vp, vp]
     L.ar_quantize.argtypes = [vp, _u8p, ctypes.c_int, ctypes.c_int, _u8p]
+    L.ar_quantize_colors.argtypes = [vp, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _u32p]
+    L.ar_read_colors.argtypes = [vp, ctypes.c_int, ctypes.c_int, _u32p]
     L.ar_set_profiling.argtypes = [vp, ctypes.c_int]
     L.ar_kernel_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), _u32p, _fp]
     L.ar_frame_counters.argtypes = [vp, _u32p]
     L.ar_set_option.argtypes = [vp, ctypes.c_int, ctypes.c_longlong]
     for name in ("ar_set_id_output", "ar_set_mesh", "ar_set_camera", "ar_set_lights", "ar_set_ascii", "ar_set_strip", "ar_set_id_output", "ar_render",
-                 "ar_render_async", "ar_sync", "ar_read", "ar_quantize", "ar_stream_wait_frame", "ar_frame_wait_stream", "ar_set_stream", "ar_set_ascii_target", "ar_set_profiling", "ar_kernel_stats",
+                 "ar_render_async", "ar_sync", "ar_read", "ar_quantize", "ar_stream_wait_frame", "ar_frame_wait_stream", "ar_set_stream", "ar_set_ascii_target", "ar_quantize_colors", "ar_read_colors", "ar_set_profiling", "ar_kernel_stats",
                  "ar_frame_counters", "ar_set_option"):
         getattr(L, name).restype = ctypes.c_int
     _lib = L
@@ -220,6 +222,22 @@ class Renderer:
             raise ValueError("rgba size does not match cols*rows*4")
         out = np.zeros((rows, cols), dtype=np.uint8)
         self._check(self._L.ar_quantize(self._h, rgba.ctypes.data_as(_u8p), int(cols), int(rows), out.ctypes.data_as(_u8p)))
+        return out
+
+    def quantize_colors(self, rgba, cols, rows, steps=0, grayscale=False):
+        """uint32[rows, cols] packed text colours of an RGBA8 grid (colour half of compositeAndQuantize)."""
+        rgba = np.ascontiguousarray(np.asarray(rgba, dtype=np.uint8).reshape(-1))
+        if rgba.size != cols * rows * 4:
+            raise ValueError("rgba size does not match cols*rows*4")
+        out = np.zeros((rows, cols), dtype=np.uint32)
+        self._check(self._L.ar_quantize_colors(self._h, rgba.ctypes.data_as(_u8p), int(cols), int(rows), int(steps),
+                                               int(bool(grayscale)), out.ctypes.data_as(_u32p)))
+        return out
+
+    def read_colors(self, steps=0, grayscale=False):
+        """Packed text colours of the last rendered frame."""
+        out = np.zeros((self.rows, self.cols), dtype=np.uint32)
+        self._check(self._L.ar_read_colors(self._h, int(steps), int(bool(grayscale)), out.ctypes.data_as(_u32p)))
         return out
 
     def set_profiling(self, on):

@@ -1070,6 +1070,22 @@ __global__ __launch_bounds__(256) void k_quantize_plain(FrameParams fp, const ui
                    : fp.ramp[ramp_index(int(me & 255u), int((me >> 8) & 255u), int((me >> 16) & 255u), fp.ramp_len)];
 }
 
+// Text colour of the DOM path (js/renderer.js:74-84): channels snapped through a 256-entry table,
+// packed (r << 16) | (g << 8) | b; alpha 2..254 (a UI cell, renderer.js:38-44) is black.
+struct ColorLut {
+    uint8_t q[256];
+};
+
+__global__ __launch_bounds__(256) void k_colors(ColorLut lut, const uint32_t *__restrict__ px, uint32_t *__restrict__ colors, size_t n) {
+    const size_t p = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t me = px[p];
+    const uint32_t a = me >> 24;
+    colors[p] = (a >= 2u && a <= 254u)
+                    ? 0u
+                    : (uint32_t(lut.q[me & 255u]) << 16) | (uint32_t(lut.q[(me >> 8) & 255u]) << 8) | uint32_t(lut.q[(me >> 16) & 255u]);
+}
+
 // Modal smoothing (ascii_pass_shader.js:77-138,169-185) over rows [row0, row1): a 32x8 tile of cells
 // per workgroup, ramp indices of the tile and its halo of R cells staged in LDS (grid-clamped, as the
 // shader's clampCell does), -1 marking alpha-override cells, which neither vote nor get smoothed.
@@ -1275,6 +1291,8 @@ struct ar_ctx {
     bool last_tiled = false;
     uint8_t *d_q_rgba = nullptr, *d_q_ascii = nullptr;
     size_t q_cells = 0;
+    uint32_t *d_q_colors = nullptr;
+    size_t qc_cells = 0;
     bool rendered = false;
     bool profiling = false;
     struct Stamp { hipEvent_t a, b; int slot; };
@@ -1618,7 +1636,7 @@ void ar_destroy(ar_ctx *ctx) {
     free_targets(ctx);
     (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx);
     (void)hipFree(ctx->d_medium); (void)hipFree(ctx->d_large); (void)hipFree(ctx->d_counters);
-    (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii);
+    (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii); (void)hipFree(ctx->d_q_colors);
     (void)hipFree(ctx->d_state); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr); (void)hipFree(ctx->d_flat);
     for (int k = 0; k < 2; k++) {
         (void)hipFree(ctx->d_entries[k]); (void)hipFree(ctx->d_surv[k]); (void)hipFree(ctx->d_surv_count[k]);
@@ -1839,6 +1857,73 @@ int ar_quantize(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *a
     AR_HIP(ctx, hipMemcpyAsync(ascii, ctx->d_q_ascii, n, hipMemcpyDeviceToHost, ctx->stream));
     AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
+}
+
+namespace {
+
+// Math.round of a non-negative double (halves up), as JavaScript rounds in qChan (js/renderer.js:30).
+double js_round(double x) {
+    double r = std::floor(x);
+    if (x - r >= 0.5) r += 1.0;
+    return r;
+}
+
+// d_rgba (device, n cells) -> colors (host).  steps <= 0: the reference's max(3, max(2, ramp length)).
+int colors_from_device(ar_ctx *ctx, const uint8_t *d_rgba, size_t n, int steps, int grayscale, uint32_t *colors) {
+    if (steps <= 0) {
+        const int rl = ctx->fp.ramp_len < 2 ? 2 : ctx->fp.ramp_len;
+        steps = rl < 3 ? 3 : rl;   // js/renderer.js:13-19
+    }
+    if (steps < 2 || steps > 256) return fail(ctx, AR_E_ARG, "colour steps %d not in 2..256", steps);
+    if (grayscale) {  // black text everywhere (renderer.js:76-77)
+        memset(colors, 0, n * sizeof(uint32_t));
+        return 0;
+    }
+    ColorLut lut;
+    const double step_val = 255.0 / double(steps - 1);
+    for (int u = 0; u < 256; u++) lut.q[u] = uint8_t(js_round(js_round((double(u) / 255.0) * double(steps - 1)) * step_val));
+    if (n > ctx->qc_cells) {
+        AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_q_colors);
+        ctx->d_q_colors = nullptr; ctx->qc_cells = 0;
+        AR_HIP(ctx, hipMalloc(&ctx->d_q_colors, n * sizeof(uint32_t)));
+        ctx->qc_cells = n;
+    }
+    k_colors<<<unsigned((n + 255) / 256), 256, 0, ctx->stream>>>(lut, reinterpret_cast<const uint32_t *>(d_rgba), ctx->d_q_colors, n);
+    AR_HIP(ctx, hipGetLastError());
+    AR_HIP(ctx, hipMemcpyAsync(colors, ctx->d_q_colors, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // namespace
+
+int ar_quantize_colors(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, int steps, int grayscale, uint32_t *colors) {
+    if (!ctx) return AR_E_ARG;
+    if (!rgba || !colors || cols <= 0 || rows <= 0 || size_t(cols) * rows > (size_t(1) << 31))
+        return fail(ctx, AR_E_ARG, "ar_quantize_colors: bad arguments (%d x %d)", cols, rows);
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = size_t(cols) * rows;
+    if (n > ctx->q_cells) {
+        AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii);
+        ctx->d_q_rgba = nullptr; ctx->d_q_ascii = nullptr; ctx->q_cells = 0;
+        AR_HIP(ctx, hipMalloc(&ctx->d_q_rgba, n * 4));
+        AR_HIP(ctx, hipMalloc(&ctx->d_q_ascii, n));
+        ctx->q_cells = n;
+    }
+    AR_HIP(ctx, hipMemcpyAsync(ctx->d_q_rgba, rgba, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    return colors_from_device(ctx, ctx->d_q_rgba, n, steps, grayscale, colors);
+}
+
+int ar_read_colors(ar_ctx *ctx, int steps, int grayscale, uint32_t *colors) {
+    if (!ctx) return AR_E_ARG;
+    if (!colors) return fail(ctx, AR_E_ARG, "ar_read_colors: null output");
+    if (!ctx->rendered) return fail(ctx, AR_E_STATE, "ar_read_colors: no frame has been rendered at this grid size");
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = sync_streams(ctx);
+    if (rc) return rc;
+    return colors_from_device(ctx, ctx->d_rgba, size_t(ctx->cols) * ctx->rows, steps, grayscale, colors);
 }
 
 int ar_set_id_output(ar_ctx *ctx, int on) {

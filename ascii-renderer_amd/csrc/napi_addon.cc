@@ -228,6 +228,25 @@ napi_value js_quantize(napi_env env, napi_callback_info info) {
     return nullptr;
 }
 
+// quantizeColors(handle, rgba, cols, rows, steps, grayscale, outUint32Array)
+napi_value js_quantize_colors(napi_env env, napi_callback_info info) {
+    napi_value argv[7];
+    if (!get_args(env, info, 7, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    void *rgba, *colors;
+    size_t nr, nc;
+    const int cols = get_i32(env, argv[2]), rows = get_i32(env, argv[3]);
+    if (!get_typed(env, argv[1], napi_uint8_array, &rgba, &nr, false) || !get_typed(env, argv[6], napi_uint32_array, &colors, &nc, false)) return nullptr;
+    const size_t n = size_t(cols > 0 ? cols : 0) * size_t(rows > 0 ? rows : 0);
+    if (nr != n * 4 || nc != n) { napi_throw_range_error(env, nullptr, "quantizeColors: array sizes do not match cols*rows"); return nullptr; }
+    bool gray = false;
+    napi_get_value_bool(env, argv[5], &gray);
+    if (ar_quantize_colors(ctx, static_cast<const uint8_t *>(rgba), cols, rows, get_i32(env, argv[4]), gray ? 1 : 0, static_cast<uint32_t *>(colors)))
+        return throw_ar(env, ctx, "ar_quantize_colors");
+    return nullptr;
+}
+
 void finalize_host(napi_env, void *data, void *) { ar_host_free(data); }
 
 // allocHost(handle, bytes) -> ArrayBuffer over page-locked host memory (freed when the buffer is collected)
@@ -284,6 +303,7 @@ napi_value init(napi_env env, napi_value exports) {
         {"quantize", nullptr, js_quantize, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"frameCounters", nullptr, js_frame_counters, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"allocHost", nullptr, js_alloc_host, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"quantizeColors", nullptr, js_quantize_colors, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     };
     napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
     return exports;

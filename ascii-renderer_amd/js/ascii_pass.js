@@ -78,6 +78,22 @@ export class AsciiPass {
     return this.draw();
   }
 
+  // Text colour per cell, packed (r << 16) | (g << 8) | b, as the reference's DOM presentation computes it
+  // (compositeAndQuantize, js/renderer.js:74-84): channels snapped to max(3, ramp length) levels so that
+  // every colour is one of the stylesheet's classes (renderer.js:162-185); UI cells (alpha 2..254) and,
+  // with opts.grayscaleText, all cells are black.  Returns this.colors (Uint32Array cols*rows).
+  colorsFromBuffer(rgbaBuffer, srcCols, srcRows) {
+    this.blit(rgbaBuffer, srcCols, srcRows);
+    if (!this._src) return this.colors;
+    if (this._src.length !== this.cols * this.rows * 4) throw new Error('AsciiPass.colorsFromBuffer: buffer does not match the grid');
+    this._ensure();
+    const N = native();
+    N.setAscii(this._h, rampBytes(this.ramp), this.modeFilter, Math.max(1, Math.min(3, this.modeRadius | 0)), this.modeThresh | 0);
+    if (!this.colors || this.colors.length !== this.cols * this.rows) this.colors = new Uint32Array(this.cols * this.rows);
+    N.quantizeColors(this._h, this._src, this.cols, this.rows, 0, !!this.grayscaleText, this.colors);
+    return this.colors;
+  }
+
   // Keeps a reference to the caller's RGBA grid (cols*rows*4); auto-resizes on mismatch
   // (ascii_pass.js:243-255).
   blit(rgbaBuffer, srcCols, srcRows) {

@@ -126,6 +126,16 @@ int ar_frame_wait_stream(ar_ctx *ctx, void *hip_stream);
  * twins compositeAndQuantize (js/renderer.js:59-72) / _computeRowString (js/text_overlay.js:128-148). */
 int ar_quantize(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *ascii);
 
+/* RGBA8 grid -> packed text colours (r << 16) | (g << 8) | b of the reference's DOM presentation.
+ * Replaces: the colour half of compositeAndQuantize (js/renderer.js:13-19,28-30,74-84): each channel
+ * snapped to `steps` levels, qChan(u8) = round(round(u8 / 255 * (steps - 1)) * 255 / (steps - 1));
+ * steps <= 0 takes the reference's max(3, ramp length) (so that colours match its stylesheet classes,
+ * renderer.js:162-185); cells with alpha 2..254 (UI cells, renderer.js:38-44) and, with grayscale set
+ * (config.USE_GRAYSCALE, renderer.js:76-77), all cells are black.
+ * ar_read_colors does the same for the RGBA plane of the last rendered frame. */
+int ar_quantize_colors(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, int steps, int grayscale, uint32_t *colors);
+int ar_read_colors(ar_ctx *ctx, int steps, int grayscale, uint32_t *colors);
+
 /* Per-kernel timing with HIP events on the context's stream.  While on, every launch is bracketed by
  * events; ar_kernel_stats drains them (blocking) and reports, per kernel slot, the number of launches
  * and the summed duration in milliseconds since the last call.  names receives static strings. */

@@ -352,3 +352,40 @@ int orc_quantize(const uint8_t *rgba, int cols, int rows, const uint8_t *ramp, i
     free(base);
     return 0;
 }
+
+/* Math.round of a non-negative double: nearest integer, halves up (ECMA-262 Math.round). */
+static double js_round(double x)
+{
+    double r = floor(x);
+    if (x - r >= 0.5) r += 1.0;
+    return r;
+}
+
+/*
+ * Colour half of compositeAndQuantize (js/renderer.js:13-19,28-30,38-44,74-84): per cell the packed
+ * text colour (r << 16) | (g << 8) | b of the DOM path.  Each channel is snapped to `steps` levels,
+ * qChan(u8) = round(round(u8 / 255 * (steps - 1)) * (255 / (steps - 1))), in binary64 as JavaScript
+ * does; steps <= 0 selects the reference's own choice max(3, max(2, ramp_len)).  UI override cells
+ * (alpha 2..254, see is_override) and every cell when grayscale is set are black (0).
+ * Pinned by colors_u32 of tests/golden/ref_quantize.json.  Returns 0, or -1 on bad arguments.
+ */
+int orc_quantize_colors(const uint8_t *rgba, int cols, int rows, int ramp_len, int steps, int grayscale,
+                        uint32_t *colors_out)
+{
+    if (cols <= 0 || rows <= 0) return -1;
+    if (steps <= 0) {
+        int rl = ramp_len < 2 ? 2 : ramp_len;
+        steps = rl < 3 ? 3 : rl;
+    }
+    if (steps < 2) return -1;
+    const double step_val = 255.0 / (double)(steps - 1);
+    uint32_t lut[256];
+    for (int u = 0; u < 256; u++)
+        lut[u] = (uint32_t)js_round(js_round(((double)u / 255.0) * (double)(steps - 1)) * step_val);
+    const size_t n = (size_t)cols * rows;
+    for (size_t p = 0; p < n; p++) {
+        if (grayscale || is_override(rgba[4 * p + 3])) { colors_out[p] = 0; continue; }
+        colors_out[p] = (lut[rgba[4 * p]] << 16) | (lut[rgba[4 * p + 1]] << 8) | lut[rgba[4 * p + 2]];
+    }
+    return 0;
+}

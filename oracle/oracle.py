@@ -103,3 +103,19 @@ def quantize(rgba, cols, rows, ramp, mode_on=0, mode_radius=2, mode_thresh=12):
     if rc != 0:
         raise ValueError("orc_quantize rejected its arguments")
     return out
+
+
+def quantize_colors(rgba, cols, rows, ramp_len, steps=0, grayscale=False):
+    """RGBA8 grid -> uint32[rows, cols] packed text colours of the DOM path (js/renderer.js:74-84)."""
+    rgba = np.ascontiguousarray(np.asarray(rgba, dtype=np.uint8).reshape(-1))
+    if rgba.size != cols * rows * 4:
+        raise ValueError("rgba size does not match cols*rows*4")
+    out = np.zeros((rows, cols), dtype=np.uint32)
+    L = lib()
+    L.orc_quantize_colors.restype = ctypes.c_int
+    rc = L.orc_quantize_colors(rgba.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ctypes.c_int(cols), ctypes.c_int(rows),
+                               ctypes.c_int(int(ramp_len)), ctypes.c_int(int(steps)), ctypes.c_int(int(bool(grayscale))),
+                               out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+    if rc != 0:
+        raise ValueError("orc_quantize_colors rejected its arguments")
+    return out

@@ -165,7 +165,7 @@ function captureRaster(RasterBackend, camera, config, scene, cam, cols, rows, pi
     for (let y = 0; y < rows; y++) { const row = []; for (let x = 0; x < cols; x++) row.push(ui ? ui[y * cols + x] : null); uiBuffer.push(row); }
     const st = { cols, rows, framebuffer: fb, uiBuffer, dataBuffer_chars: new Uint16Array(cols * rows), dataBuffer_colors: new Uint32Array(cols * rows) };
     compositeAndQuantize(st);
-    return { chars: st.dataBuffer_chars, alpha_after: fb.filter((_, i) => i % 4 === 3) };
+    return { chars: st.dataBuffer_chars, colors: st.dataBuffer_colors, alpha_after: fb.filter((_, i) => i % 4 === 3) };
   }
   // exhaustive: every sum 0..765 (three different splits of each sum)
   {
@@ -180,7 +180,7 @@ function captureRaster(RasterBackend, camera, config, scene, cam, cols, rows, pi
     }
     for (const ramp of ramps) {
       const o = runQuant(ramp, cols, rows, rgba, null);
-      quant.cases.push({ name: 'exhaustive_sums', ramp, cols, rows, rgba: b64(rgba), chars_u16: b64(o.chars) });
+      quant.cases.push({ name: 'exhaustive_sums', ramp, cols, rows, rgba: b64(rgba), chars_u16: b64(o.chars), colors_u32: b64(o.colors) });
     }
   }
   // random grids with UI overrides
@@ -193,7 +193,7 @@ function captureRaster(RasterBackend, camera, config, scene, cam, cols, rows, pi
       for (let i = 0; i < cols * rows; i++) { const u = rq(); ui.push(u < 0.15 ? String.fromCharCode(32 + ((rq() * 95) | 0)) : null); }
       for (const ramp of ramps.slice(0, 3)) {
         const o = runQuant(ramp, cols, rows, rgba, ui);
-        quant.cases.push({ name: 'random_ui', ramp, cols, rows, rgba: b64(rgba), ui: ui.map((c) => (c === null ? 0 : c.charCodeAt(0))), chars_u16: b64(o.chars), alpha_after_u8: b64(new Uint8Array(o.alpha_after)) });
+        quant.cases.push({ name: 'random_ui', ramp, cols, rows, rgba: b64(rgba), ui: ui.map((c) => (c === null ? 0 : c.charCodeAt(0))), chars_u16: b64(o.chars), colors_u32: b64(o.colors), alpha_after_u8: b64(new Uint8Array(o.alpha_after)) });
       }
     }
   }

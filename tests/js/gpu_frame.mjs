@@ -64,6 +64,9 @@ const dump = (name, ta) => fs.writeFileSync(path.join(outDir, name), Buffer.from
   for (let i = 0; i < text.length; i++) { const p = (5 * 640 + 10 + i) * 4; ui[p] = ui[p + 1] = ui[p + 2] = 0; ui[p + 3] = text.charCodeAt(i) & 0xFF; }
   const pass = new AsciiPass();
   const codes = pass.drawFromBuffer(ui, 640, 360);
+  const colors = pass.colorsFromBuffer(ui, 640, 360);
+  if (!(colors instanceof Uint32Array) || colors.length !== 640 * 360) throw new Error('colorsFromBuffer shape');
+  dump('ico_ui.colors', colors);
   dump('ico_ui.rgba', ui); dump('ico_ui.codes', codes);
   meta.row5 = pass.rowString(5).slice(10, 10 + text.length);
   pass.dispose();

@@ -340,6 +340,35 @@ def test_quantize_entry_point_vs_reference_vectors(pkg, oracle, R, golden_dir):
         assert np.array_equal(got.reshape(-1).astype(np.uint16), want), (case["name"], case["ramp"])
 
 
+def test_text_colours_vs_reference_vectors_and_oracle(pkg, oracle, R, golden_dir):
+    """ar_quantize_colors against the reference's dataBuffer_colors, and ar_read_colors of a rendered
+    frame against the oracle's colours of the oracle's frame."""
+    with open(os.path.join(golden_dir, "ref_quantize.json")) as fh:
+        ref = json.load(fh)
+    for case in ref["cases"]:
+        rgba = np.frombuffer(base64.b64decode(case["rgba"]), dtype=np.uint8).copy()
+        want = np.frombuffer(base64.b64decode(case["colors_u32"]), dtype=np.uint32)
+        if "ui" in case:
+            ui = np.asarray(case["ui"], dtype=np.uint8)
+            rgba.reshape(-1, 4)[:, 3] = np.where(ui > 0, ui, 1)
+        else:
+            rgba.reshape(-1, 4)[:, 3] = 255
+        R.set_ascii(case["ramp"], False, 2, 12)
+        got = R.quantize_colors(rgba, case["cols"], case["rows"])
+        assert np.array_equal(got.reshape(-1), want), (case["name"], case["ramp"])
+        assert not R.quantize_colors(rgba, case["cols"], case["rows"], grayscale=True).any()
+    sc = pkg.scenes.icosphere_scene(point_lights=3)
+    pkg.scenes.upload(R, sc)
+    R.render(sc["cols"], sc["rows"])
+    rgba, _d, _i = oracle.render(sc["vbo"], sc["idx"], sc["proj"], sc["view"], sc["lights"], sc["cols"], sc["rows"])
+    for steps in (0, 2, 5, 256):
+        want = oracle.quantize_colors(rgba, sc["cols"], sc["rows"], len(pkg.scenes.DEFAULT_RAMP), steps)
+        assert np.array_equal(R.read_colors(steps), want), steps
+    assert np.unique(R.read_colors()).size > 20
+    with pytest.raises(pkg.AsciiRastError):
+        R.read_colors(1)
+
+
 def test_quantize_modal_vs_oracle(pkg, oracle, R):
     rng = np.random.default_rng(3)
     for cols, rows, radius, thresh in [(96, 36, 2, 12), (333, 77, 3, 20), (5, 3, 1, 3), (1920, 1080, 2, 12)]:

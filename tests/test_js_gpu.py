@@ -48,3 +48,6 @@ def test_node_harness_frames_match_oracle(pkg, oracle, tmp_path):
     ui = np.fromfile(tmp_path / "ico_ui.rgba", dtype=np.uint8)
     codes = np.fromfile(tmp_path / "ico_ui.codes", dtype=np.uint8).reshape(360, 640)
     assert np.array_equal(codes, oracle.quantize(ui, 640, 360, ramp, 1, 2, 12))
+    colors = np.fromfile(tmp_path / "ico_ui.colors", dtype=np.uint32).reshape(360, 640)
+    assert np.array_equal(colors, oracle.quantize_colors(ui, 640, 360, len(ramp)))
+    assert np.unique(colors).size > 10 and not colors[5, 10:21].any()      # the UI text cells are black

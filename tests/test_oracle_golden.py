@@ -37,6 +37,29 @@ def test_quantize_matches_compositeAndQuantize(oracle, ref):
         assert np.array_equal(got.reshape(-1).astype(np.uint16), want), (case["name"], case["ramp"])
 
 
+def _with_ui_alpha(case, rgba):
+    if "ui" in case:
+        ui = np.asarray(case["ui"], dtype=np.uint8)
+        rgba.reshape(-1, 4)[:, 3] = np.where(ui > 0, ui, 1)
+    else:
+        rgba.reshape(-1, 4)[:, 3] = 255
+    return rgba
+
+
+def test_text_colours_match_compositeAndQuantize(oracle, ref):
+    """dataBuffer_colors of the reference (js/renderer.js:74-84) for every recorded grid and ramp; the
+    number of levels per channel follows the ramp length as in renderer.js:13-19."""
+    seen = set()
+    for case in ref["cases"]:
+        rgba, _ = _case_arrays(case)
+        want = np.frombuffer(base64.b64decode(case["colors_u32"]), dtype=np.uint32)
+        got = oracle.quantize_colors(_with_ui_alpha(case, rgba), case["cols"], case["rows"], len(case["ramp"]))
+        assert np.array_equal(got.reshape(-1), want), (case["name"], case["ramp"])
+        seen.add(max(3, len(case["ramp"])))
+        assert not oracle.quantize_colors(rgba, case["cols"], case["rows"], len(case["ramp"]), grayscale=True).any()
+    assert len(seen) >= 4          # several step counts are covered (3, 10, 12, 70)
+
+
 def test_alpha_written_by_reference_is_the_override_convention(ref):
     for case in ref["cases"]:
         if "ui" not in case:
