@@ -140,6 +140,16 @@ def main():
     R.set_profiling(False)
     counters = R.frame_counters()
 
+    gather_ok = None
+    if gather:
+        # the gathered grid of the last frame must be the full frame: compare with this rank's own full render
+        torch.cuda.synchronize()
+        R.set_strip(0, 0)
+        R.set_ascii_target(None)
+        full = torch.from_numpy(R.render(args.cols, args.rows)["ascii"]).cuda()
+        gather_ok = bool(torch.equal(full, batcher.frame(batcher.gathered - 1)))
+        if not gather_ok:
+            print("rank %d: gathered ASCII grid differs from a full-frame render" % rank, file=sys.stderr, flush=True)
     if rank == 0:
         cells = args.cols * (row1 - row0)
         per_launch_bytes = {                             # algorithmic bytes one launch must move
@@ -181,20 +191,13 @@ def main():
                        "queued_records": counters},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic},
+            "gather_verified": gather_ok,
             "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
             "kernels_avg_us_serial": {k: round(v, 2) for k, v in kern_serial.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ar, sc)
         print(json.dumps(line), flush=True)
-    if gather:
-        # the gathered grid of the last frame must be the full frame: compare with this rank's own full render
-        torch.cuda.synchronize()
-        R.set_strip(0, 0)
-        R.set_ascii_target(None)
-        full = torch.from_numpy(R.render(args.cols, args.rows)["ascii"]).cuda()
-        if not torch.equal(full, batcher.frame(batcher.gathered - 1)):
-            raise SystemExit("rank %d: gathered ASCII grid differs from a full-frame render" % rank)
     R.close()
     if gather:
         dist.barrier()
