@@ -9,12 +9,12 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libascii_rast.so")
-N_KERNELS = 11
+N_KERNELS = 12
 EXPORTS = [
     "ar_create", "ar_destroy", "ar_last_error", "ar_set_mesh", "ar_set_camera", "ar_set_lights",
     "ar_set_ascii", "ar_set_strip", "ar_set_id_output", "ar_render", "ar_render_async", "ar_sync", "ar_read",
     "ar_device_buffer", "ar_stream", "ar_host_alloc", "ar_host_free", "ar_stream_wait_frame", "ar_frame_wait_stream", "ar_set_stream",
-    "ar_set_ascii_target", "ar_quantize", "ar_quantize_colors", "ar_read_colors", "ar_set_profiling", "ar_kernel_stats",
+    "ar_set_ascii_target", "ar_quantize", "ar_quantize_colors", "ar_read_colors", "ar_present", "ar_set_profiling", "ar_kernel_stats",
     "ar_frame_counters", "ar_set_option",
 ]
 _lib = None
@@ -70,12 +70,14 @@ def load_library():
     L.ar_quantize.argtypes = [vp, _u8p, ctypes.c_int, ctypes.c_int, _u8p]
     L.ar_quantize_colors.argtypes = [vp, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _u32p]
     L.ar_read_colors.argtypes = [vp, ctypes.c_int, ctypes.c_int, _u32p]
+    L.ar_present.argtypes = [vp, _u8p, ctypes.c_int, ctypes.c_int, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                             ctypes.c_int, ctypes.c_int, _u8p]
     L.ar_set_profiling.argtypes = [vp, ctypes.c_int]
     L.ar_kernel_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), _u32p, _fp]
     L.ar_frame_counters.argtypes = [vp, _u32p]
     L.ar_set_option.argtypes = [vp, ctypes.c_int, ctypes.c_longlong]
     for name in ("ar_set_id_output", "ar_set_mesh", "ar_set_camera", "ar_set_lights", "ar_set_ascii", "ar_set_strip", "ar_set_id_output", "ar_render",
-                 "ar_render_async", "ar_sync", "ar_read", "ar_quantize", "ar_stream_wait_frame", "ar_frame_wait_stream", "ar_set_stream", "ar_set_ascii_target", "ar_quantize_colors", "ar_read_colors", "ar_set_profiling", "ar_kernel_stats",
+                 "ar_render_async", "ar_sync", "ar_read", "ar_quantize", "ar_stream_wait_frame", "ar_frame_wait_stream", "ar_set_stream", "ar_set_ascii_target", "ar_quantize_colors", "ar_read_colors", "ar_present", "ar_set_profiling", "ar_kernel_stats",
                  "ar_frame_counters", "ar_set_option"):
         getattr(L, name).restype = ctypes.c_int
     _lib = L
@@ -232,6 +234,19 @@ class Renderer:
         out = np.zeros((rows, cols), dtype=np.uint32)
         self._check(self._L.ar_quantize_colors(self._h, rgba.ctypes.data_as(_u8p), int(cols), int(rows), int(steps),
                                                int(bool(grayscale)), out.ctypes.data_as(_u32p)))
+        return out
+
+    def present(self, rgba, cols, rows, atlas, cell_w, cell_h, gamma=1.0, grayscale=False, transparent_bg=False, out=None):
+        """uint8[rows*cell_h, cols*cell_w, 4] image of the ASCII grid drawn with the caller's glyph atlas."""
+        rgba = np.ascontiguousarray(np.asarray(rgba, dtype=np.uint8).reshape(-1))
+        atlas = np.ascontiguousarray(np.asarray(atlas, dtype=np.uint8).reshape(-1))
+        if rgba.size != cols * rows * 4 or atlas.size != 256 * (cell_w + 4) * (cell_h + 4):
+            raise ValueError("present: array sizes do not match the grid / atlas layout")
+        if out is None:
+            out = np.zeros((rows * cell_h, cols * cell_w, 4), dtype=np.uint8)
+        self._check(self._L.ar_present(self._h, rgba.ctypes.data_as(_u8p), int(cols), int(rows), atlas.ctypes.data_as(_u8p),
+                                       int(cell_w), int(cell_h), float(gamma), int(bool(grayscale)), int(bool(transparent_bg)),
+                                       out.ctypes.data_as(_u8p)))
         return out
 
     def read_colors(self, steps=0, grayscale=False):

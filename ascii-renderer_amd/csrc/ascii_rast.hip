@@ -39,10 +39,10 @@ constexpr int kMediumMaxCells = 4096;   // above this a record goes to the per-c
 constexpr uint32_t kMediumCapacity = 1u << 18;
 constexpr uint32_t kLargeCapacity = 1u << 14;
 
-enum KernelSlot { K_CLEAR = 0, K_RASTER, K_MEDIUM, K_LARGE, K_SHADE, K_ASCII, K_SETUP, K_BINSCAN, K_BINOFF, K_FILL, K_TILE };
+enum KernelSlot { K_CLEAR = 0, K_RASTER, K_MEDIUM, K_LARGE, K_SHADE, K_ASCII, K_SETUP, K_BINSCAN, K_BINOFF, K_FILL, K_TILE, K_PRESENT };
 const char *const kKernelNames[AR_N_KERNELS] = {"k_clear",  "k_raster", "k_raster_medium", "k_raster_large",
                                                 "k_shade", "k_ascii",  "k_setup",         "k_binscan",
-                                                "k_binoffsets", "k_fill", "k_tile"};
+                                                "k_binoffsets", "k_fill", "k_tile", "k_present"};
 
 // Everything a frame's kernels need besides the big buffers; passed by value as a kernel argument.
 struct FrameParams {
@@ -1086,6 +1086,72 @@ __global__ __launch_bounds__(256) void k_colors(ColorLut lut, const uint32_t *__
                     : (uint32_t(lut.q[me & 255u]) << 16) | (uint32_t(lut.q[(me >> 8) & 255u]) << 8) | uint32_t(lut.q[(me >> 16) & 255u]);
 }
 
+// Glyph compositing (js/ascii_pass_shader.js:190-230) onto a canvas of cols*cell_w x rows*cell_h pixels,
+// row 0 = top.  A lane produces four consecutive pixels of one canvas row (one 16-byte store): per pixel the glyph's atlas
+// texel (nearest; 2 pixels of tile padding skipped), coverage = cov[alpha] (the shader's pow(alpha,
+// gamma), tabulated on the host), colour = mix(1, tint, coverage) per channel in binary32, bytes rounded
+// like the raster stage's.  A streaming kernel: 4 bytes written per pixel, the per-cell inputs and the
+// atlas are re-read from cache.
+struct PresentParams {
+    int cols, rows, cell_w, cell_h, W, H, atlas_w, tile_w, tile_h;
+    int grayscale, transparent_bg, vec_store;
+    float inv_cell_w;  // 1 / cell_w: (X + 0.5) * inv_cell_w truncates to X / cell_w for every X below 2^20
+};
+
+__global__ __launch_bounds__(256) void k_present(PresentParams pp, const uint32_t *__restrict__ px, const uint8_t *__restrict__ codes,
+                                                 const uint8_t *__restrict__ atlas, const float *__restrict__ cov_of,
+                                                 uint32_t *__restrict__ image) {
+    __shared__ float cov[256], unit[256];  // coverage per alpha byte, colour byte / 255
+    cov[threadIdx.x] = cov_of[threadIdx.x];
+    unit[threadIdx.x] = float(threadIdx.x) / 255.0f;
+    __syncthreads();
+    const int X0 = (int(blockIdx.x) * 256 + int(threadIdx.x)) * 4, Y = int(blockIdx.y);
+    if (X0 >= pp.W) return;
+    const int cy = Y / pp.cell_h, py = Y - cy * pp.cell_h;  // uniform over the workgroup
+    int cx = int((float(X0) + 0.5f) * pp.inv_cell_w), pxl = X0 - cx * pp.cell_w;
+    uint32_t out[4];
+    float tint[3] = {0.0f, 0.0f, 0.0f};
+    const uint8_t *trow = nullptr;
+    int loaded = -1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        out[k] = 0u;
+        if (X0 + k < pp.W) {
+            if (loaded != cx) {
+                const size_t cell = size_t(cy) * pp.cols + cx;
+                const uint32_t cell_px = px[cell];
+                if (!pp.grayscale) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) tint[ch] = unit[(cell_px >> (8 * ch)) & 255u];
+                }
+                const int g = codes[cell];
+                trow = atlas + size_t((g >> 4) * pp.tile_h + 2 + py) * pp.atlas_w + (g & 15) * pp.tile_w + 2;
+                loaded = cx;
+            }
+            const float c = cov[trow[pxl]];
+            if (!(pp.transparent_bg && c <= 0.0f)) {
+                uint32_t v = 0xFF000000u;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    float o = (1.0f - c) + tint[ch] * c;
+                    o = fminf(fmaxf(o, 0.0f), 1.0f);
+                    v |= uint32_t(floorf(o * 255.0f + 0.5f)) << (8 * ch);
+                }
+                out[k] = v;
+            }
+        }
+        if (++pxl == pp.cell_w) { pxl = 0; cx++; }
+    }
+    uint32_t *dst = image + size_t(Y) * pp.W + X0;
+    if (pp.vec_store) {
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (X0 + k < pp.W) dst[k] = out[k];
+    }
+}
+
 // Modal smoothing (ascii_pass_shader.js:77-138,169-185) over rows [row0, row1): a 32x8 tile of cells
 // per workgroup, ramp indices of the tile and its halo of R cells staged in LDS (grid-clamped, as the
 // shader's clampCell does), -1 marking alpha-override cells, which neither vote nor get smoothed.
@@ -1293,6 +1359,8 @@ struct ar_ctx {
     size_t q_cells = 0;
     uint32_t *d_q_colors = nullptr;
     size_t qc_cells = 0;
+    uint8_t *d_p_atlas = nullptr; float *d_p_cov = nullptr; uint32_t *d_p_image = nullptr;  // ar_present scratch
+    size_t p_atlas_bytes = 0, p_pixels = 0;
     bool rendered = false;
     bool profiling = false;
     struct Stamp { hipEvent_t a, b; int slot; };
@@ -1637,6 +1705,7 @@ void ar_destroy(ar_ctx *ctx) {
     (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx);
     (void)hipFree(ctx->d_medium); (void)hipFree(ctx->d_large); (void)hipFree(ctx->d_counters);
     (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii); (void)hipFree(ctx->d_q_colors);
+    (void)hipFree(ctx->d_p_atlas); (void)hipFree(ctx->d_p_cov); (void)hipFree(ctx->d_p_image);
     (void)hipFree(ctx->d_state); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr); (void)hipFree(ctx->d_flat);
     for (int k = 0; k < 2; k++) {
         (void)hipFree(ctx->d_entries[k]); (void)hipFree(ctx->d_surv[k]); (void)hipFree(ctx->d_surv_count[k]);
@@ -1831,10 +1900,10 @@ int ar_frame_wait_stream(ar_ctx *ctx, void *hip_stream) {
     return 0;
 }
 
-int ar_quantize(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *ascii) {
-    if (!ctx) return AR_E_ARG;
-    if (!rgba || !ascii || cols <= 0 || rows <= 0 || size_t(cols) * rows > (size_t(1) << 31))
-        return fail(ctx, AR_E_ARG, "ar_quantize: bad arguments (%d x %d)", cols, rows);
+namespace {
+
+// Host RGBA grid -> d_q_rgba and its ASCII codes -> d_q_ascii, enqueued on the context's stream.
+int quantize_to_device(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows) {
     AR_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n = size_t(cols) * rows;
     if (n > ctx->q_cells) {
@@ -1854,7 +1923,63 @@ int ar_quantize(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *a
         else k_quantize_plain<<<unsigned((n + 255) / 256), 256, 0, ctx->stream>>>(fp, reinterpret_cast<const uint32_t *>(ctx->d_q_rgba), ctx->d_q_ascii, n);
     }
     AR_HIP(ctx, hipGetLastError());
-    AR_HIP(ctx, hipMemcpyAsync(ascii, ctx->d_q_ascii, n, hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
+}  // namespace
+
+int ar_quantize(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *ascii) {
+    if (!ctx) return AR_E_ARG;
+    if (!rgba || !ascii || cols <= 0 || rows <= 0 || size_t(cols) * rows > (size_t(1) << 31))
+        return fail(ctx, AR_E_ARG, "ar_quantize: bad arguments (%d x %d)", cols, rows);
+    int rc = quantize_to_device(ctx, rgba, cols, rows);
+    if (rc) return rc;
+    AR_HIP(ctx, hipMemcpyAsync(ascii, ctx->d_q_ascii, size_t(cols) * rows, hipMemcpyDeviceToHost, ctx->stream));
+    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ar_present(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, const uint8_t *atlas_alpha, int cell_w, int cell_h,
+               double alpha_gamma, int grayscale, int transparent_bg, uint8_t *image) {
+    if (!ctx) return AR_E_ARG;
+    if (!rgba || !atlas_alpha || !image || cols <= 0 || rows <= 0 || cell_w <= 0 || cell_h <= 0 || cell_w > 1024 || cell_h > 1024 ||
+        size_t(cols) * rows > (size_t(1) << 31) || size_t(cols) * cell_w > (size_t(1) << 20) || size_t(rows) * cell_h > 65535u ||
+        !(alpha_gamma > 0.0))
+        return fail(ctx, AR_E_ARG, "ar_present: bad arguments (%d x %d cells of %d x %d pixels, gamma %g)", cols, rows, cell_w, cell_h, alpha_gamma);
+    int rc = quantize_to_device(ctx, rgba, cols, rows);
+    if (rc) return rc;
+    PresentParams pp;
+    pp.cols = cols; pp.rows = rows; pp.cell_w = cell_w; pp.cell_h = cell_h;
+    pp.W = cols * cell_w; pp.H = rows * cell_h;
+    pp.tile_w = cell_w + 4; pp.tile_h = cell_h + 4; pp.atlas_w = 16 * pp.tile_w;
+    pp.grayscale = grayscale ? 1 : 0; pp.transparent_bg = transparent_bg ? 1 : 0; pp.vec_store = (pp.W % 4) == 0 ? 1 : 0;
+    pp.inv_cell_w = 1.0f / float(cell_w);
+    const size_t atlas_bytes = size_t(pp.atlas_w) * 16 * pp.tile_h, pixels = size_t(pp.W) * pp.H;
+    if (atlas_bytes > ctx->p_atlas_bytes || !ctx->d_p_cov) {
+        AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_p_atlas); ctx->d_p_atlas = nullptr; ctx->p_atlas_bytes = 0;
+        AR_HIP(ctx, hipMalloc(&ctx->d_p_atlas, atlas_bytes));
+        ctx->p_atlas_bytes = atlas_bytes;
+        if (!ctx->d_p_cov) AR_HIP(ctx, hipMalloc(&ctx->d_p_cov, 256 * sizeof(float)));
+    }
+    if (pixels > ctx->p_pixels) {
+        AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_p_image); ctx->d_p_image = nullptr; ctx->p_pixels = 0;
+        AR_HIP(ctx, hipMalloc(&ctx->d_p_image, pixels * sizeof(uint32_t)));
+        ctx->p_pixels = pixels;
+    }
+    float cov_of[256];
+    for (int a = 0; a < 256; a++) cov_of[a] = alpha_gamma == 1.0 ? float(a) / 255.0f : float(std::pow(double(a) / 255.0, alpha_gamma));
+    AR_HIP(ctx, hipMemcpyAsync(ctx->d_p_atlas, atlas_alpha, atlas_bytes, hipMemcpyHostToDevice, ctx->stream));
+    AR_HIP(ctx, hipMemcpyAsync(ctx->d_p_cov, cov_of, sizeof cov_of, hipMemcpyHostToDevice, ctx->stream));
+    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // cov_of lives on this stack frame
+    {
+        Stamper s(ctx, K_PRESENT);
+        k_present<<<dim3(unsigned((pp.W + 1023) / 1024), unsigned(pp.H)), 256, 0, ctx->stream>>>(
+            pp, reinterpret_cast<const uint32_t *>(ctx->d_q_rgba), ctx->d_q_ascii, ctx->d_p_atlas, ctx->d_p_cov, ctx->d_p_image);
+    }
+    AR_HIP(ctx, hipGetLastError());
+    AR_HIP(ctx, hipMemcpyAsync(image, ctx->d_p_image, pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }

@@ -247,6 +247,35 @@ napi_value js_quantize_colors(napi_env env, napi_callback_info info) {
     return nullptr;
 }
 
+// present(handle, rgba, cols, rows, atlasAlpha, cellW, cellH, gamma, grayscale, transparentBg, outImage)
+napi_value js_present(napi_env env, napi_callback_info info) {
+    napi_value argv[11];
+    if (!get_args(env, info, 11, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    void *rgba, *atlas, *image;
+    size_t nr, na, ni;
+    const int cols = get_i32(env, argv[2]), rows = get_i32(env, argv[3]), cw = get_i32(env, argv[5]), ch = get_i32(env, argv[6]);
+    if (!get_typed(env, argv[1], napi_uint8_array, &rgba, &nr, false) || !get_typed(env, argv[4], napi_uint8_array, &atlas, &na, false) ||
+        !get_typed(env, argv[10], napi_uint8_array, &image, &ni, false))
+        return nullptr;
+    if (cols <= 0 || rows <= 0 || cw <= 0 || ch <= 0) { napi_throw_range_error(env, nullptr, "present: bad grid or cell size"); return nullptr; }
+    const size_t n = size_t(cols) * size_t(rows);
+    if (nr != n * 4 || na != size_t(256) * size_t(cw + 4) * size_t(ch + 4) || ni != n * size_t(cw) * size_t(ch) * 4) {
+        napi_throw_range_error(env, nullptr, "present: array sizes do not match the grid / atlas layout");
+        return nullptr;
+    }
+    double gamma = 1.0;
+    bool gray = false, transparent = false;
+    napi_get_value_double(env, argv[7], &gamma);
+    napi_get_value_bool(env, argv[8], &gray);
+    napi_get_value_bool(env, argv[9], &transparent);
+    if (ar_present(ctx, static_cast<const uint8_t *>(rgba), cols, rows, static_cast<const uint8_t *>(atlas), cw, ch, gamma, gray ? 1 : 0,
+                   transparent ? 1 : 0, static_cast<uint8_t *>(image)))
+        return throw_ar(env, ctx, "ar_present");
+    return nullptr;
+}
+
 void finalize_host(napi_env, void *data, void *) { ar_host_free(data); }
 
 // allocHost(handle, bytes) -> ArrayBuffer over page-locked host memory (freed when the buffer is collected)
@@ -304,6 +333,7 @@ napi_value init(napi_env env, napi_value exports) {
         {"frameCounters", nullptr, js_frame_counters, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"allocHost", nullptr, js_alloc_host, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"quantizeColors", nullptr, js_quantize_colors, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"present", nullptr, js_present, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     };
     napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
     return exports;

@@ -78,6 +78,27 @@ export class AsciiPass {
     return this.draw();
   }
 
+  // The whole pass, pixels included: RGBA8 image (Uint8ClampedArray, cols*cellW x rows*cellH, row 0 = top) of
+  // the grid drawn with the caller's glyph atlas - what the reference's draw() leaves on its canvas
+  // (js/ascii_pass_shader.js:190-230) with this.alphaGamma, this.grayscaleText and this.transparentBackground.
+  // atlasAlpha is the alpha plane of the atlas buildAtlas would bake (ascii_pass.js:20-60) for
+  // this.cellWDevice x this.cellHDevice cells: 16 x 16 tiles of (cellW + 4) x (cellH + 4) bytes.
+  present(rgbaBuffer, srcCols, srcRows, atlasAlpha) {
+    this.blit(rgbaBuffer, srcCols, srcRows);
+    if (!this._src) return null;
+    if (this._src.length !== this.cols * this.rows * 4) throw new Error('AsciiPass.present: buffer does not match the grid');
+    const a = this._atlas;
+    if (!atlasAlpha || atlasAlpha.length !== a.count * a.tileW * a.tileH) throw new Error('AsciiPass.present: atlas does not match the cell size');
+    this._ensure();
+    const N = native();
+    N.setAscii(this._h, rampBytes(this.ramp), this.modeFilter, Math.max(1, Math.min(3, this.modeRadius | 0)), this.modeThresh | 0);
+    const n = this.cols * this.cellWDevice * this.rows * this.cellHDevice * 4;
+    if (!this.image || this.image.length !== n) this.image = new Uint8ClampedArray(n);
+    N.present(this._h, this._src, this.cols, this.rows, atlasAlpha, this.cellWDevice, this.cellHDevice, this.alphaGamma,
+      !!this.grayscaleText, !!this.transparentBackground, this.image);
+    return this.image;
+  }
+
   // Text colour per cell, packed (r << 16) | (g << 8) | b, as the reference's DOM presentation computes it
   // (compositeAndQuantize, js/renderer.js:74-84): channels snapped to max(3, ramp length) levels so that
   // every colour is one of the stylesheet's classes (renderer.js:162-185); UI cells (alpha 2..254) and,

@@ -126,6 +126,18 @@ int ar_frame_wait_stream(ar_ctx *ctx, void *hip_stream);
  * twins compositeAndQuantize (js/renderer.js:59-72) / _computeRowString (js/text_overlay.js:128-148). */
 int ar_quantize(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *ascii);
 
+/* RGBA8 grid -> RGBA8 image of coloured glyphs, cols*cell_w x rows*cell_h pixels, row 0 = top.
+ * Replaces: AsciiPass.drawFromBuffer in full - the index half as ar_quantize, then the compositing half of
+ * the fragment shader (js/ascii_pass_shader.js:190-230): per pixel the nearest texel of the cell's glyph,
+ * coverage = pow(alpha / 255, alpha_gamma) (uAlphaGamma), colour = mix(white, cell colour, coverage)
+ * (black text when grayscale, uGray), alpha 255; with transparent_bg (uTransparentBG) pixels of zero
+ * coverage are (0,0,0,0) instead of white.  atlas_alpha is the alpha plane of the reference's glyph atlas
+ * layout (js/ascii_pass.js:20-60): 16 x 16 tiles of (cell_w + 4) x (cell_h + 4) bytes (2 bytes of padding
+ * all round), glyph g at tile (g % 16, g / 16), row 0 = top; the reference bakes it with a canvas font,
+ * here the caller supplies it.  The canvas is exactly cols*cell_w x rows*cell_h (at most 2^20 pixels wide and 65535 pixel rows). */
+int ar_present(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, const uint8_t *atlas_alpha, int cell_w, int cell_h,
+               double alpha_gamma, int grayscale, int transparent_bg, uint8_t *image);
+
 /* RGBA8 grid -> packed text colours (r << 16) | (g << 8) | b of the reference's DOM presentation.
  * Replaces: the colour half of compositeAndQuantize (js/renderer.js:13-19,28-30,74-84): each channel
  * snapped to `steps` levels, qChan(u8) = round(round(u8 / 255 * (steps - 1)) * 255 / (steps - 1));
@@ -139,7 +151,7 @@ int ar_read_colors(ar_ctx *ctx, int steps, int grayscale, uint32_t *colors);
 /* Per-kernel timing with HIP events on the context's stream.  While on, every launch is bracketed by
  * events; ar_kernel_stats drains them (blocking) and reports, per kernel slot, the number of launches
  * and the summed duration in milliseconds since the last call.  names receives static strings. */
-#define AR_N_KERNELS 11
+#define AR_N_KERNELS 12
 int ar_set_profiling(ar_ctx *ctx, int on);
 int ar_kernel_stats(ar_ctx *ctx, const char *names[AR_N_KERNELS], uint32_t launches[AR_N_KERNELS], float total_ms[AR_N_KERNELS]);
 

@@ -389,3 +389,48 @@ int orc_quantize_colors(const uint8_t *rgba, int cols, int rows, int ramp_len, i
     }
     return 0;
 }
+
+/*
+ * Glyph compositing of the ASCII pass (js/ascii_pass_shader.js:190-230) for a canvas of exactly
+ * cols*cell_w x rows*cell_h device pixels.  PARITY UNPINNED (the reference does this in WebGL and
+ * bakes its atlas with a browser font); this function is the definition the HIP kernel follows.
+ *   codes       cols*rows glyph indices (output of orc_quantize), rgba the grid they came from
+ *   atlas       alpha plane of a 16 x 16 tile atlas, tile = (cell_w + 4) x (cell_h + 4) with 2 pixels of
+ *               padding, glyph g at tile (g % 16, g / 16) (js/ascii_pass.js:20-60), row 0 = top of the glyphs
+ *   image       RGBA8, row 0 = top; pixel (X, Y) belongs to cell (X / cell_w, Y / cell_h) and reads the
+ *               atlas texel (pad + X % cell_w, pad + Y % cell_h) of its glyph's tile (nearest, :46-47)
+ *   cov = pow(alpha / 255, gamma) evaluated in binary64 and rounded to binary32 (gamma == 1: alpha / 255 in
+ *   binary32); tint = cell colour / 255 (0 when grayscale); out = (1 - cov) + tint * cov per channel in
+ *   binary32 (mix(vec3(1), tint, cov)), byte = floor(clamp(out, 0, 1) * 255 + 0.5), alpha 255;
+ *   with transparent_bg a pixel whose cov <= 0 is (0, 0, 0, 0) (the shader discards it).
+ */
+int orc_present(const uint8_t *rgba, const uint8_t *codes, int cols, int rows, const uint8_t *atlas, int cell_w,
+                int cell_h, double gamma, int grayscale, int transparent_bg, uint8_t *image)
+{
+    if (cols <= 0 || rows <= 0 || cell_w <= 0 || cell_h <= 0) return -1;
+    const int pad = 2, tile_w = cell_w + 2 * pad, tile_h = cell_h + 2 * pad, atlas_w = 16 * tile_w;
+    float cov_of[256];
+    for (int a = 0; a < 256; a++)
+        cov_of[a] = (gamma == 1.0) ? (float)a / 255.0f : (float)pow((double)a / 255.0, gamma);
+    const size_t W = (size_t)cols * cell_w;
+    for (int cy = 0; cy < rows; cy++)
+        for (int py = 0; py < cell_h; py++)
+            for (int cx = 0; cx < cols; cx++) {
+                const size_t cell = (size_t)cy * cols + cx;
+                const int g = codes[cell];
+                const uint8_t *trow = atlas + (size_t)((g / 16) * tile_h + pad + py) * atlas_w + (g % 16) * tile_w + pad;
+                uint8_t *out = image + (((size_t)cy * cell_h + py) * W + (size_t)cx * cell_w) * 4;
+                for (int px = 0; px < cell_w; px++, out += 4) {
+                    const float cov = cov_of[trow[px]];
+                    if (transparent_bg && cov <= 0.0f) { out[0] = out[1] = out[2] = out[3] = 0; continue; }
+                    for (int ch = 0; ch < 3; ch++) {
+                        const float tint = grayscale ? 0.0f : (float)rgba[4 * cell + ch] / 255.0f;
+                        float v = (1.0f - cov) + tint * cov;
+                        v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+                        out[ch] = (uint8_t)floorf(v * 255.0f + 0.5f);
+                    }
+                    out[3] = 255;
+                }
+            }
+    return 0;
+}

@@ -119,3 +119,22 @@ def quantize_colors(rgba, cols, rows, ramp_len, steps=0, grayscale=False):
     if rc != 0:
         raise ValueError("orc_quantize_colors rejected its arguments")
     return out
+
+
+def present(rgba, codes, cols, rows, atlas, cell_w, cell_h, gamma=1.0, grayscale=False, transparent_bg=False):
+    """Glyph compositing: uint8[rows*cell_h, cols*cell_w, 4] image of the ASCII grid (ascii_pass_shader.js:190-230)."""
+    rgba = np.ascontiguousarray(np.asarray(rgba, dtype=np.uint8).reshape(-1))
+    codes = np.ascontiguousarray(np.asarray(codes, dtype=np.uint8).reshape(-1))
+    atlas = np.ascontiguousarray(np.asarray(atlas, dtype=np.uint8).reshape(-1))
+    if rgba.size != cols * rows * 4 or codes.size != cols * rows or atlas.size != 256 * (cell_w + 4) * (cell_h + 4):
+        raise ValueError("present: array sizes do not match the grid / atlas layout")
+    out = np.zeros((rows * cell_h, cols * cell_w, 4), dtype=np.uint8)
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    L = lib()
+    L.orc_present.restype = ctypes.c_int
+    rc = L.orc_present(rgba.ctypes.data_as(u8p), codes.ctypes.data_as(u8p), ctypes.c_int(cols), ctypes.c_int(rows),
+                       atlas.ctypes.data_as(u8p), ctypes.c_int(cell_w), ctypes.c_int(cell_h), ctypes.c_double(gamma),
+                       ctypes.c_int(int(bool(grayscale))), ctypes.c_int(int(bool(transparent_bg))), out.ctypes.data_as(u8p))
+    if rc != 0:
+        raise ValueError("orc_present rejected its arguments")
+    return out

@@ -67,6 +67,18 @@ const dump = (name, ta) => fs.writeFileSync(path.join(outDir, name), Buffer.from
   const colors = pass.colorsFromBuffer(ui, 640, 360);
   if (!(colors instanceof Uint32Array) || colors.length !== 640 * 360) throw new Error('colorsFromBuffer shape');
   dump('ico_ui.colors', colors);
+  // pixels: the 96x36 cube frame drawn with the baked 8x16 atlas fixture
+  {
+    const atlas = new Uint8Array(fs.readFileSync(path.join(here, '..', 'golden', 'atlas_8x16.bin')));
+    const small = new AsciiPass(null, { cellW: 8, cellH: 16, dpr: 1, transparentBackground: false });
+    small.setCellSize(8, 16);
+    const f3 = frame('cube_small', sceneApi.meshScene(cube), cam, 96, 36);
+    const img = small.present(f3.fb, 96, 36, atlas);
+    if (!(img instanceof Uint8ClampedArray) || img.length !== 96 * 8 * 36 * 16 * 4) throw new Error('present shape');
+    dump('cube_small.image', img);
+    meta.present = { cellW: small.cellWDevice, cellH: small.cellHDevice, gamma: small.alphaGamma };
+    small.dispose();
+  }
   dump('ico_ui.rgba', ui); dump('ico_ui.codes', codes);
   meta.row5 = pass.rowString(5).slice(10, 10 + text.length);
   pass.dispose();

@@ -369,6 +369,37 @@ def test_text_colours_vs_reference_vectors_and_oracle(pkg, oracle, R, golden_dir
         R.read_colors(1)
 
 
+def test_glyph_compositing_vs_oracle(pkg, oracle, R, golden_dir):
+    """ar_present (index half + glyph compositing, ascii_pass_shader.js:140-230) against the oracle: random
+    and baked atlases, cell sizes with and without 16-byte row alignment, gamma, grayscale, transparent
+    background, UI override cells.  Parity unpinned against the reference (WebGL + browser font)."""
+    rng = np.random.default_rng(11)
+    baked = np.fromfile(os.path.join(golden_dir, "atlas_8x16.bin"), dtype=np.uint8)
+    ramp = pkg.scenes.DEFAULT_RAMP
+    cases = [(96, 36, 8, 16, baked, 1.2, False, True), (96, 36, 8, 16, baked, 1.0, False, False), (37, 11, 5, 7, None, 1.2, False, False),
+             (64, 20, 8, 16, None, 0.7, True, True), (3, 2, 1, 1, None, 1.0, False, True), (130, 50, 6, 13, None, 2.2, False, False)]
+    for cols, rows, cw, ch, atlas, gamma, gray, transparent in cases:
+        if atlas is None:
+            atlas = rng.integers(0, 256, size=256 * (cw + 4) * (ch + 4), dtype=np.uint8)
+            atlas[rng.random(atlas.size) < 0.4] = 0
+        rgba = rng.integers(0, 256, size=(rows, cols, 4), dtype=np.uint8)
+        rgba[:, :, 3] = np.where(rng.random((rows, cols)) < 0.1, rng.integers(32, 127, size=(rows, cols)), 255)
+        R.set_ascii(ramp, True, 2, 12)
+        codes = oracle.quantize(rgba, cols, rows, ramp, 1, 2, 12)
+        want = oracle.present(rgba, codes, cols, rows, atlas, cw, ch, gamma, gray, transparent)
+        got = R.present(rgba, cols, rows, atlas, cw, ch, gamma, gray, transparent)
+        assert np.array_equal(got, want), (cols, rows, cw, ch, gamma, gray, transparent, np.count_nonzero(got != want))
+        assert transparent or (got[:, :, 3] == 255).all()
+    sc = pkg.scenes.icosphere_scene(cols=96, rows=36)
+    pkg.scenes.upload(R, sc)
+    frame = R.render(96, 36)
+    img = R.present(frame["rgba"], 96, 36, baked, 8, 16, 1.2, False, False)
+    assert np.array_equal(img, oracle.present(frame["rgba"], frame["ascii"], 96, 36, baked, 8, 16, 1.2, False, False))
+    assert 0.02 < np.mean(img[:, :, :3] < 250) < 0.9          # glyph ink on white
+    with pytest.raises(pkg.AsciiRastError):
+        R.present(frame["rgba"], 96, 36, baked, 8, 16, 0.0)
+
+
 def test_quantize_modal_vs_oracle(pkg, oracle, R):
     rng = np.random.default_rng(3)
     for cols, rows, radius, thresh in [(96, 36, 2, 12), (333, 77, 3, 20), (5, 3, 1, 3), (1920, 1080, 2, 12)]:

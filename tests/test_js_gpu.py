@@ -24,6 +24,7 @@ def test_node_harness_frames_match_oracle(pkg, oracle, tmp_path):
     meshes = {
         "cube": (pkg.geometry.cube(0.5), None),
         "cube_mesh": (pkg.geometry.cube(0.5), None),
+        "cube_small": (pkg.geometry.cube(0.5), None),
         "ico": (pkg.geometry.icosphere(4, 1.0),
                 {"lights": {"points": [{"p": [2, 1.5, 0], "color": [1, 0.6, 0.5], "intensity": 3},
                                        {"p": [-1, 1.5, 1.7], "color": [1, 0.7, 0.5], "intensity": 3}]}}),
@@ -45,6 +46,13 @@ def test_node_harness_frames_match_oracle(pkg, oracle, tmp_path):
         assert np.array_equal(got_depth.view(np.uint32), depth.view(np.uint32)), fr["name"]
         assert np.array_equal(got_ascii, asc), fr["name"]
         assert np.count_nonzero(rgba[:, :, :3]) > 30 and np.count_nonzero(depth < 1.0) > 100
+    pr = meta["present"]
+    assert (pr["cellW"], pr["cellH"]) == (8, 16) and abs(pr["gamma"] - 1.2) < 1e-12
+    atlas = np.fromfile(os.path.join(ROOT, "tests", "golden", "atlas_8x16.bin"), dtype=np.uint8)
+    small = np.fromfile(tmp_path / "cube_small.rgba", dtype=np.uint8)
+    img = np.fromfile(tmp_path / "cube_small.image", dtype=np.uint8).reshape(36 * 16, 96 * 8, 4)
+    want = oracle.present(small, oracle.quantize(small, 96, 36, ramp, 1, 2, 12), 96, 36, atlas, 8, 16, 1.2, False, False)
+    assert np.array_equal(img, want)
     ui = np.fromfile(tmp_path / "ico_ui.rgba", dtype=np.uint8)
     codes = np.fromfile(tmp_path / "ico_ui.codes", dtype=np.uint8).reshape(360, 640)
     assert np.array_equal(codes, oracle.quantize(ui, 640, 360, ramp, 1, 2, 12))
