@@ -935,12 +935,18 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
     __shared__ uint16_t covered[kTileCells];
     __shared__ uint32_t n_list, n_big, n_cov;
     const uint32_t tid = threadIdx.x;
-    const int tile_x = int(blockIdx.x) % fp.ntx, tile_y = int(blockIdx.x) / fp.ntx;
+    // Workgroups are handed to the eight XCDs round-robin and each XCD has its own L2: the tiles of one
+    // bin, which all read the bin's entry array, are given workgroup numbers that are equal modulo 8.
+    // Workgroup B = 8 * tiles_per_bin * g + 8 * k + x is tile k of bin 8 g + x.
+    const int side = 1 << fp.bshift, tiles_per_bin = side * side;
+    const int wg_group = int(blockIdx.x) / (8 * tiles_per_bin), wg_in = int(blockIdx.x) % (8 * tiles_per_bin);
+    const int bin = wg_group * 8 + (wg_in & 7), sub = wg_in >> 3;
+    if (bin >= fp.nbx * fp.nby) return;
+    const int tile_x = (bin % fp.nbx) * side + (sub & (side - 1)), tile_y = (bin / fp.nbx) * side + (sub >> fp.bshift);
+    if (tile_x >= fp.ntx || tile_y >= fp.nty) return;
     const int tx0 = tile_x * kTileW, tr0 = fp.ya + tile_y * kTileH;                      // first column / output row
     const int tx1 = min(tx0 + kTileW, fp.cols) - 1, tr1 = min(tr0 + kTileH, fp.yb) - 1;  // last column / row
-    const int side = 1 << fp.bshift;
-    const int bin = (tile_y >> fp.bshift) * fp.nbx + (tile_x >> fp.bshift);
-    const uint32_t bit = 1u << ((tile_y & (side - 1)) * side + (tile_x & (side - 1)));
+    const uint32_t bit = 1u << sub;
     const BinState &st = state[fp.frame & 1u];
     for (int c = int(tid); c < kTileCells; c += 256) keys[c] = kBackgroundKey;
     if (tid == 0) { n_list = 0; n_big = 0; n_cov = 0; }
@@ -1598,7 +1604,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
         }
         {
             Stamper s(ctx, K_TILE);
-            k_tile<<<unsigned(nt), 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_tripos, ctx->tripos_stride,
+            k_tile<<<unsigned((nbins + 7) / 8 * 8) << (2 * fp.bshift), 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_tripos, ctx->tripos_stride,
                                                          ctx->d_records[set], ctx->d_entries[set], ctx->pool_cap, ctx->d_state,
                                                          ctx->d_vis[set], ctx->d_rgba, ctx->d_depth, ascii_out, ctx->d_ridx[set],
                                                          ctx->d_ids);

@@ -2,6 +2,8 @@
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ar = importlib.import_module("ascii-renderer_amd")
+if os.environ.get("AR_LIB"):
+    ar.binding.LIB_PATH = os.environ["AR_LIB"]
 tris = int(os.environ.get("AR_TRIS", "1000000")); cols = int(os.environ.get("AR_COLS", "1920")); rows = int(os.environ.get("AR_ROWS", "1080"))
 sc = ar.scenes.random_scene(tris, cols, rows)
 R = ar.Renderer(0)
