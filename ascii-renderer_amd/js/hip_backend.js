@@ -248,6 +248,10 @@ export class HipRasterBackend {
     return fb;
   }
 
+  // Page-locked planes for the optional appState.ascii (Uint8Array) / appState.depth (Float32Array) outputs.
+  allocAsciiPlane(cols, rows) { this._ensure(); return new Uint8Array(native().allocHost(this._h, cols * rows)); }
+  allocDepthPlane(cols, rows) { this._ensure(); return new Float32Array(native().allocHost(this._h, cols * rows * 4)); }
+
   _ensure() {
     if (this._h) return;
     this._h = native().create(this._device);
