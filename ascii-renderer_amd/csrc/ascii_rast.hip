@@ -1315,6 +1315,7 @@ struct ar_ctx {
     int device = 0;
     hipStream_t stream = nullptr;   // pixel stream: tile resolve, shading, copies (own_stream, or the caller's: ar_set_stream)
     hipStream_t own_stream = nullptr;
+    bool overlapped_in_flight = false;  // an overlapped frame was enqueued since the last full synchronisation
     bool ext_stream = false;        // stream is the caller's: every kernel goes there, frames do not overlap
     uint8_t *ascii_target = nullptr;  // caller's device buffer for the ASCII plane (ar_set_ascii_target), else d_ascii
     int target_row = 0;               // frame row stored at ascii_target
@@ -1421,6 +1422,7 @@ struct Stamper {  // brackets one launch with events when profiling is on
 };
 
 int sync_streams(ar_ctx *ctx) {
+    ctx->overlapped_in_flight = false;
     if (ctx->stream != ctx->own_stream) AR_HIP(ctx, hipStreamSynchronize(ctx->own_stream));
     AR_HIP(ctx, hipStreamSynchronize(ctx->gstream));
     AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1467,7 +1469,9 @@ int ensure_targets(ar_ctx *ctx, int cols, int rows) {
     return 0;
 }
 
-int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
+// may_overlap: the caller does not wait for this frame right away (a blocking frame gains nothing from the
+// three-stream schedule and would pay for its events)
+int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
     if (cols <= 0 || rows <= 0 || size_t(cols) * rows > (size_t(1) << 31))
         return fail(ctx, AR_E_ARG, "ar_render: bad grid %d x %d", cols, rows);
     AR_HIP(ctx, hipSetDevice(ctx->device));
@@ -1505,7 +1509,12 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows) {
     const int set = int(ctx->frame & 1u);  // buffer set of this frame (tiled path)
     // the cross-stream events of an overlapped frame cost the host about as much as 40 us of GPU time:
     // below that much work per frame the single-stream schedule is the faster one
-    const bool overlap = !ctx->ext_stream && (ctx->overlap == 1 || (ctx->overlap == 2 && ctx->n_tris >= 100000u));
+    const bool overlap = may_overlap && !ctx->ext_stream && (ctx->overlap == 1 || (ctx->overlap == 2 && ctx->n_tris >= 100000u));
+    if (!overlap && ctx->overlapped_in_flight) {  // frames still running on the other streams
+        rc = sync_streams(ctx);
+        if (rc) return rc;
+    }
+    if (overlap) ctx->overlapped_in_flight = true;
     uint8_t *ascii_out = ctx->ascii_target ? ctx->ascii_target - ptrdiff_t(ctx->target_row) * cols : ctx->d_ascii;
     if (tiled != ctx->last_tiled && ctx->rendered) {
         // the two paths share the key buffers and do not order themselves against each other's streams
@@ -1807,7 +1816,7 @@ int ar_set_strip(ar_ctx *ctx, int row0, int row1) {
 
 int ar_render_async(ar_ctx *ctx, int cols, int rows) {
     if (!ctx) return AR_E_ARG;
-    return enqueue_frame(ctx, cols, rows);
+    return enqueue_frame(ctx, cols, rows, true);
 }
 
 int ar_sync(ar_ctx *ctx) {
@@ -1835,7 +1844,7 @@ int ar_read(ar_ctx *ctx, uint8_t *rgba, float *depth, uint8_t *ascii, uint32_t *
 
 int ar_render(ar_ctx *ctx, int cols, int rows, uint8_t *rgba, float *depth, uint8_t *ascii) {
     if (!ctx) return AR_E_ARG;
-    int rc = enqueue_frame(ctx, cols, rows);
+    int rc = enqueue_frame(ctx, cols, rows, false);
     if (rc) return rc;
     if (ctx->n_tris == 0 || !ctx->rendered) return ar_sync(ctx);  // no geometry: outputs stay untouched (raster.js:274)
     return ar_read(ctx, rgba, depth, ascii, nullptr);
