@@ -61,7 +61,8 @@ struct FrameParams {
     int nbx, nby;    // bin grid
     int bshift;      // a bin is (1 << bshift)^2 tiles: 0 while the tiles fit the bin table, else 1
     uint32_t chunk, n_groups;  // triangles per k_setup workgroup, number of those workgroups
-    uint32_t frame;  // frame counter (selects the binning state block)
+    uint32_t frame;  // frame counter
+    int set;         // buffer set of this frame (frame % kSets): binning state block, record slots, ...
     uint8_t ramp[AR_MAX_RAMP];
 };
 
@@ -471,9 +472,10 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__re
 // If the entry pool cannot hold a bin, the sub-triangles touching that bin are rasterised straight
 // into a global key buffer by k_fill, k_binoffsets raises the frame's overflow flag and k_tile merges
 // that buffer in.
-// Everything these kernels write exists twice (by frame parity), so that consecutive frames can
-// overlap: see enqueue_frame.
+// Everything a frame writes exists kSets times, so that consecutive frames can overlap: see
+// enqueue_frame.
 // ------------------------------------------------------------------------------------------------
+constexpr int kSets = 2;               // frames in flight: every per-frame buffer exists kSets times
 constexpr int kTileW = 64, kTileH = 32, kTileCells = kTileW * kTileH;
 constexpr int kMaxTiles = 8000;       // tiles per frame the tiled path accepts
 constexpr int kMaxBins = 2048;        // >= kMaxTiles / 4 for any tile-grid shape the path accepts
@@ -494,8 +496,7 @@ struct __align__(16) BinRec {
 };
 static_assert(sizeof(BinRec) == 64, "bin records are four 16-byte loads");
 
-// Per-frame binning state; one block per frame parity, like every other buffer the binning kernels
-// write, so that the binning of frame f+1 can run while frame f's tiles are still being resolved.
+// Per-frame binning state; one block per buffer set.
 struct BinState {
     uint32_t total[kMaxBins];
     uint32_t start[kMaxBins];   // exclusive scan of total (k_binoffsets)
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(1024) void k_binoffsets(FrameParams fp, const uint3
     __shared__ uint32_t s_wave[16];
     const int nbins = fp.nbx * fp.nby;
     const uint32_t tid = threadIdx.x;
-    BinState &st = state[fp.frame & 1u];
+    BinState &st = state[fp.set];
     const int b0 = 2 * int(tid), b1 = b0 + 1;  // kMaxBins == 2 * 1024
     uint32_t x0[16], x1[16], t0 = 0, t1 = 0;
 #pragma unroll
@@ -758,7 +759,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Bi
     __shared__ uint8_t fits[kMaxBins];
     const uint32_t tid = threadIdx.x;
     const int nbins = fp.nbx * fp.nby;
-    const BinState &st = state[fp.frame & 1u];
+    const BinState &st = state[fp.set];
     const uint32_t rows_per_block = (fp.n_groups + 15u) / 16u;
     const uint32_t my_block = blockIdx.x / rows_per_block;
     const uint32_t n = surv_count[blockIdx.x];
@@ -947,7 +948,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
     const int tx0 = tile_x * kTileW, tr0 = fp.ya + tile_y * kTileH;                      // first column / output row
     const int tx1 = min(tx0 + kTileW, fp.cols) - 1, tr1 = min(tr0 + kTileH, fp.yb) - 1;  // last column / row
     const uint32_t bit = 1u << sub;
-    const BinState &st = state[fp.frame & 1u];
+    const BinState &st = state[fp.set];
     for (int c = int(tid); c < kTileCells; c += 256) keys[c] = kBackgroundKey;
     if (tid == 0) { n_list = 0; n_big = 0; n_cov = 0; }
     const uint32_t e_begin = st.start[bin];
@@ -1313,19 +1314,16 @@ thread_local char g_create_error[256] = "";
 
 struct ar_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;   // pixel stream: tile resolve, shading, copies (own_stream, or the caller's: ar_set_stream)
+    hipStream_t stream = nullptr;   // stream of frames that do not overlap, of quantize / present and of copies: own_stream
+                                    // or the caller's (ar_set_stream)
     hipStream_t own_stream = nullptr;
+    hipStream_t fstream[kSets] = {};  // overlapped frames: frame f runs entirely on fstream[f % kSets]; [0] is own_stream
     bool overlapped_in_flight = false;  // an overlapped frame was enqueued since the last full synchronisation
     bool ext_stream = false;        // stream is the caller's: every kernel goes there, frames do not overlap
     uint8_t *ascii_target = nullptr;  // caller's device buffer for the ASCII plane (ar_set_ascii_target), else d_ascii
     int target_row = 0;               // frame row stored at ascii_target
-    hipStream_t gstream = nullptr;  // geometry stream: setup and binning of the next frame run beside the pixel work
-    hipEvent_t ev_fill[2] = {nullptr, nullptr};  // per buffer set: binning of the frame using it is complete
-    hipEvent_t ev_tile[2] = {nullptr, nullptr};  // per buffer set: the tiles of the frame using it are resolved
-    hipStream_t astream = nullptr;  // ASCII stream: smoothing of frame f beside the tile resolve of frame f+1
-    hipEvent_t ev_ascii[2] = {nullptr, nullptr}; // per ramp-index plane: the smoothing pass that reads it is done
-    int overlap = 2;                // 0: everything on the pixel stream, 1: frames overlap on three streams, 2: decide per frame
-    hipEvent_t ev_out[2] = {nullptr, nullptr};  // outputs complete on the pixel / ASCII stream (ar_stream_wait_frame)
+    int overlap = 2;                // 0: frames one after the other on `stream`; 1, 2: consecutive frames alternate streams
+    hipEvent_t ev_out[kSets + 1] = {};  // outputs complete on each frame stream / on `stream` (ar_stream_wait_frame)
     hipEvent_t ev_ext = nullptr;    // a caller's stream has consumed the outputs (ar_frame_wait_stream)
     float *d_vbo = nullptr;
     uint32_t *d_idx = nullptr;
@@ -1334,12 +1332,14 @@ struct ar_ctx {
     FrameParams fp;
     int strip0 = 0, strip1 = 0;
     int cols = 0, rows = 0;  // size of the current targets
-    uint64_t *d_vis[2] = {nullptr, nullptr};  // global key buffers ([0] direct path; tiled path: overflow keys of the frame parity)
-    uint8_t *d_rgba = nullptr;
-    float *d_depth = nullptr;
-    uint8_t *d_ascii = nullptr;
-    uint8_t *d_ridx[2] = {nullptr, nullptr};  // ramp index per cell (input of the smoothing pass), by frame parity on the tiled path
-    uint32_t *d_ids = nullptr;   // winner per cell, allocated when id output is switched on
+    uint64_t *d_vis[kSets] = {};  // global key buffers ([0] direct path; tiled path: overflow keys of the frame's set)
+    // outputs, per buffer set while frames overlap (frames that do not overlap always use set 0)
+    uint8_t *d_rgba[kSets] = {};
+    float *d_depth[kSets] = {};
+    uint8_t *d_ascii[kSets] = {};
+    int last_oset = 0;           // output set of the most recent frame
+    uint8_t *d_ridx[kSets] = {};  // ramp index per cell (input of the smoothing pass)
+    uint32_t *d_ids[kSets] = {};  // winner per cell, allocated when id output is switched on
     bool want_ids = false;
     bool vis_clean = false;      // every key of d_vis[*] is "background" (the consuming kernels restore this each frame)
     TriRec *d_medium = nullptr, *d_large = nullptr;
@@ -1350,16 +1350,16 @@ struct ar_ctx {
     float *d_tripos = nullptr;       // 9 planes x tripos_stride floats: triangle positions
     size_t tripos_stride = 0;
     float *d_triattr = nullptr;      // n_tris x 24 floats: the three vertices' normals and colours
-    // everything the binning kernels write exists twice, indexed by frame parity
-    BinRec *d_records[2] = {nullptr, nullptr};  // 2 x n_tris setup record slots, filled densely per k_setup workgroup
+    // everything the binning kernels write, per buffer set
+    BinRec *d_records[kSets] = {};  // 2 x n_tris setup record slots, filled densely per k_setup workgroup
     uint8_t *d_flat = nullptr;       // n_tris flags: identical normal and colour at the three vertices
-    uint4 *d_surv[2] = {nullptr, nullptr};  // per k_setup workgroup: (id, cell range, flags) of its surviving sub-triangles
-    uint32_t *d_surv_count[2] = {nullptr, nullptr};
-    uint32_t *d_dircount[2] = {nullptr, nullptr};  // per k_setup workgroup: entries per bin (+ scan scratch)
+    uint4 *d_surv[kSets] = {};  // per k_setup workgroup: (id, cell range, flags) of its surviving sub-triangles
+    uint32_t *d_surv_count[kSets] = {};
+    uint32_t *d_dircount[kSets] = {};  // per k_setup workgroup: entries per bin (+ scan scratch)
     size_t group_cap = 0, dircount_cap = 0;
-    unsigned long long *d_entries[2] = {nullptr, nullptr};  // (record slot, tile mask) entries grouped by bin
+    unsigned long long *d_entries[kSets] = {};  // (record slot, tile mask) entries grouped by bin
     uint32_t pool_cap = 0;
-    BinState *d_state = nullptr;     // two blocks, indexed by frame parity
+    BinState *d_state = nullptr;     // kSets blocks
     uint32_t frame = 0;              // tiled frames enqueued so far
     bool last_tiled = false;
     uint8_t *d_q_rgba = nullptr, *d_q_ascii = nullptr;
@@ -1423,21 +1423,22 @@ struct Stamper {  // brackets one launch with events when profiling is on
 
 int sync_streams(ar_ctx *ctx) {
     ctx->overlapped_in_flight = false;
-    if (ctx->stream != ctx->own_stream) AR_HIP(ctx, hipStreamSynchronize(ctx->own_stream));
-    AR_HIP(ctx, hipStreamSynchronize(ctx->gstream));
-    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    AR_HIP(ctx, hipStreamSynchronize(ctx->astream));
+    for (int k = 0; k < kSets; k++) AR_HIP(ctx, hipStreamSynchronize(ctx->fstream[k]));
+    if (ctx->stream != ctx->own_stream) AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
 int free_targets(ar_ctx *ctx) {
-    (void)hipFree(ctx->d_vis[0]); (void)hipFree(ctx->d_vis[1]); (void)hipFree(ctx->d_rgba); (void)hipFree(ctx->d_depth);
-    (void)hipFree(ctx->d_ascii); (void)hipFree(ctx->d_ridx[0]); (void)hipFree(ctx->d_ridx[1]); (void)hipFree(ctx->d_ids);
-    ctx->d_vis[0] = ctx->d_vis[1] = nullptr; ctx->d_rgba = nullptr; ctx->d_depth = nullptr; ctx->d_ascii = nullptr;
-    ctx->d_ridx[0] = ctx->d_ridx[1] = nullptr; ctx->d_ids = nullptr;
+    for (int k = 0; k < kSets; k++) {
+        (void)hipFree(ctx->d_vis[k]); (void)hipFree(ctx->d_rgba[k]); (void)hipFree(ctx->d_depth[k]); (void)hipFree(ctx->d_ascii[k]);
+        (void)hipFree(ctx->d_ridx[k]); (void)hipFree(ctx->d_ids[k]);
+        ctx->d_vis[k] = nullptr; ctx->d_rgba[k] = nullptr; ctx->d_depth[k] = nullptr; ctx->d_ascii[k] = nullptr;
+        ctx->d_ridx[k] = nullptr; ctx->d_ids[k] = nullptr;
+    }
     ctx->cols = ctx->rows = 0;
     ctx->rendered = false;
     ctx->vis_clean = false;
+    ctx->last_oset = 0;
     return 0;
 }
 
@@ -1447,30 +1448,38 @@ int ensure_targets(ar_ctx *ctx, int cols, int rows) {
         int rc = sync_streams(ctx);
         if (rc) return rc;
         free_targets(ctx);
-        AR_HIP(ctx, hipMalloc(&ctx->d_vis[0], n * sizeof(uint64_t)));
-        AR_HIP(ctx, hipMalloc(&ctx->d_vis[1], n * sizeof(uint64_t)));
-        AR_HIP(ctx, hipMalloc(&ctx->d_rgba, n * 4));
-        AR_HIP(ctx, hipMalloc(&ctx->d_depth, n * sizeof(float)));
-        AR_HIP(ctx, hipMalloc(&ctx->d_ascii, n));
-        AR_HIP(ctx, hipMalloc(&ctx->d_ridx[0], n));
-        AR_HIP(ctx, hipMalloc(&ctx->d_ridx[1], n));
-        // rows outside a strip are never written by the kernels: give them defined contents once
-        AR_HIP(ctx, hipMemsetAsync(ctx->d_rgba, 0, n * 4, ctx->stream));
-        AR_HIP(ctx, hipMemsetAsync(ctx->d_depth, 0, n * sizeof(float), ctx->stream));
-        AR_HIP(ctx, hipMemsetAsync(ctx->d_ascii, 0, n, ctx->stream));
-        AR_HIP(ctx, hipMemsetAsync(ctx->d_ridx[0], 0, n, ctx->stream));
-        AR_HIP(ctx, hipMemsetAsync(ctx->d_ridx[1], 0, n, ctx->stream));
+        for (int k = 0; k < kSets; k++) {
+            AR_HIP(ctx, hipMalloc(&ctx->d_vis[k], n * sizeof(uint64_t)));
+            AR_HIP(ctx, hipMalloc(&ctx->d_rgba[k], n * 4));
+            AR_HIP(ctx, hipMalloc(&ctx->d_depth[k], n * sizeof(float)));
+            AR_HIP(ctx, hipMalloc(&ctx->d_ascii[k], n));
+            AR_HIP(ctx, hipMalloc(&ctx->d_ridx[k], n));
+            // rows outside a strip are never written by the kernels: give them defined contents once
+            AR_HIP(ctx, hipMemsetAsync(ctx->d_rgba[k], 0, n * 4, ctx->stream));
+            AR_HIP(ctx, hipMemsetAsync(ctx->d_depth[k], 0, n * sizeof(float), ctx->stream));
+            AR_HIP(ctx, hipMemsetAsync(ctx->d_ascii[k], 0, n, ctx->stream));
+            AR_HIP(ctx, hipMemsetAsync(ctx->d_ridx[k], 0, n, ctx->stream));
+        }
+        AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->cols = cols; ctx->rows = rows;
     }
-    if (ctx->want_ids && !ctx->d_ids) {
-        AR_HIP(ctx, hipMalloc(&ctx->d_ids, n * sizeof(uint32_t)));
-        AR_HIP(ctx, hipMemsetAsync(ctx->d_ids, 0xFF, n * sizeof(uint32_t), ctx->stream));
+    if (ctx->want_ids && !ctx->d_ids[0]) {
+        int rc = sync_streams(ctx);
+        if (rc) return rc;
+        for (int k = 0; k < kSets; k++) {
+            AR_HIP(ctx, hipMalloc(&ctx->d_ids[k], n * sizeof(uint32_t)));
+            AR_HIP(ctx, hipMemsetAsync(ctx->d_ids[k], 0xFF, n * sizeof(uint32_t), ctx->stream));
+        }
+        AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return 0;
 }
 
-// may_overlap: the caller does not wait for this frame right away (a blocking frame gains nothing from the
-// three-stream schedule and would pay for its events)
+// Frames whose caller does not wait for them right away (may_overlap) run entirely on one of kSets frame
+// streams, frame f on stream f % kSets, and every buffer a frame writes exists kSets times: consecutive
+// frames share the GPU without a single cross-stream event (each of which costs the host about as much as
+// two kernel launches), and frame f + kSets follows frame f on the same stream, which is all the ordering
+// the reuse of a buffer set needs.
 int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
     if (cols <= 0 || rows <= 0 || size_t(cols) * rows > (size_t(1) << 31))
         return fail(ctx, AR_E_ARG, "ar_render: bad grid %d x %d", cols, rows);
@@ -1506,16 +1515,16 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
     const size_t nbins = size_t(fp.nbx) * fp.nby;
     const bool tiled = ctx->path == 0 && nt <= size_t(kMaxTiles) && nbins <= size_t(kMaxBins) && cols <= 65535 &&
                        rows <= 65535 && ctx->d_tripos;
-    const int set = int(ctx->frame & 1u);  // buffer set of this frame (tiled path)
-    // the cross-stream events of an overlapped frame cost the host about as much as 40 us of GPU time:
-    // below that much work per frame the single-stream schedule is the faster one
-    const bool overlap = may_overlap && !ctx->ext_stream && (ctx->overlap == 1 || (ctx->overlap == 2 && ctx->n_tris >= 100000u));
-    if (!overlap && ctx->overlapped_in_flight) {  // frames still running on the other streams
+    const int set = int(ctx->frame % unsigned(kSets));  // buffer set of this frame (tiled path)
+    const bool overlap = tiled && may_overlap && !ctx->ext_stream && ctx->overlap != 0;
+    if (!overlap && ctx->overlapped_in_flight) {  // frames still running on the frame streams
         rc = sync_streams(ctx);
         if (rc) return rc;
     }
     if (overlap) ctx->overlapped_in_flight = true;
-    uint8_t *ascii_out = ctx->ascii_target ? ctx->ascii_target - ptrdiff_t(ctx->target_row) * cols : ctx->d_ascii;
+    hipStream_t fs = overlap ? ctx->fstream[set] : ctx->stream;  // the stream of this frame
+    const int oset = overlap ? set : 0;                          // its output buffers
+    uint8_t *ascii_out = ctx->ascii_target ? ctx->ascii_target - ptrdiff_t(ctx->target_row) * cols : ctx->d_ascii[oset];
     if (tiled != ctx->last_tiled && ctx->rendered) {
         // the two paths share the key buffers and do not order themselves against each other's streams
         rc = sync_streams(ctx);
@@ -1528,25 +1537,26 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
         fp.chunk = chunk;
         fp.n_groups = (fp.n_tris + chunk - 1) / chunk;
         fp.frame = ctx->frame;
+        fp.set = set;
         const uint32_t want_cap = ctx->pool_cap_option ? ctx->pool_cap_option : 2u * fp.n_tris + 65536u;
         if (!ctx->d_entries[0] || ctx->pool_cap != want_cap) {
             rc = sync_streams(ctx);
             if (rc) return rc;
-            for (int k = 0; k < 2; k++) { (void)hipFree(ctx->d_entries[k]); ctx->d_entries[k] = nullptr; }
+            for (int k = 0; k < kSets; k++) { (void)hipFree(ctx->d_entries[k]); ctx->d_entries[k] = nullptr; }
             ctx->pool_cap = 0;
-            for (int k = 0; k < 2; k++) AR_HIP(ctx, hipMalloc(&ctx->d_entries[k], size_t(want_cap) * sizeof(unsigned long long)));
+            for (int k = 0; k < kSets; k++) AR_HIP(ctx, hipMalloc(&ctx->d_entries[k], size_t(want_cap) * sizeof(unsigned long long)));
             ctx->pool_cap = want_cap;
         }
         const size_t want_groups = size_t(fp.n_groups) * 2 * chunk;
         if (!ctx->d_surv[0] || ctx->group_cap < want_groups) {
             rc = sync_streams(ctx);
             if (rc) return rc;
-            for (int k = 0; k < 2; k++) {
+            for (int k = 0; k < kSets; k++) {
                 (void)hipFree(ctx->d_surv[k]); (void)hipFree(ctx->d_surv_count[k]);
                 ctx->d_surv[k] = nullptr; ctx->d_surv_count[k] = nullptr;
             }
             ctx->group_cap = 0;
-            for (int k = 0; k < 2; k++) {
+            for (int k = 0; k < kSets; k++) {
                 AR_HIP(ctx, hipMalloc(&ctx->d_surv[k], want_groups * sizeof(uint4)));
                 AR_HIP(ctx, hipMalloc(&ctx->d_surv_count[k], (size_t(kMaxGroups) + 1) * sizeof(uint32_t)));
             }
@@ -1556,9 +1566,9 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
         if (!ctx->d_dircount[0] || ctx->dircount_cap < want_dir) {
             rc = sync_streams(ctx);
             if (rc) return rc;
-            for (int k = 0; k < 2; k++) { (void)hipFree(ctx->d_dircount[k]); ctx->d_dircount[k] = nullptr; }
+            for (int k = 0; k < kSets; k++) { (void)hipFree(ctx->d_dircount[k]); ctx->d_dircount[k] = nullptr; }
             ctx->dircount_cap = 0;
-            for (int k = 0; k < 2; k++) AR_HIP(ctx, hipMalloc(&ctx->d_dircount[k], (want_dir + 32 * size_t(kMaxBins)) * sizeof(uint32_t)));
+            for (int k = 0; k < kSets; k++) AR_HIP(ctx, hipMalloc(&ctx->d_dircount[k], (want_dir + 32 * size_t(kMaxBins)) * sizeof(uint32_t)));
             ctx->dircount_cap = want_dir;
         }
     }
@@ -1571,54 +1581,41 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
         rc = sync_streams(ctx);
         if (rc) return rc;
         AR_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
-        AR_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, 2 * sizeof(BinState), ctx->stream));
+        AR_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, kSets * sizeof(BinState), ctx->stream));
         {
             Stamper s(ctx, K_CLEAR);
-            k_clear<<<2048, 256, 0, ctx->stream>>>(ctx->d_vis[0], 0, size_t(cols) * rows);
-            k_clear<<<2048, 256, 0, ctx->stream>>>(ctx->d_vis[1], 0, size_t(cols) * rows);
+            for (int k = 0; k < kSets; k++) k_clear<<<2048, 256, 0, ctx->stream>>>(ctx->d_vis[k], 0, size_t(cols) * rows);
         }
         AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     if (tiled) {
-        // Binning of frame f runs on the geometry stream and may overlap the pixel work of frame f-1;
-        // it only has to wait until the tiles of frame f-2 (the last user of this buffer set) are done.
-        hipStream_t gs = overlap ? ctx->gstream : ctx->stream;
         uint32_t *dircount = ctx->d_dircount[set];
         uint32_t *blocksum = dircount + ctx->dircount_cap, *boff = blocksum + 16 * size_t(kMaxBins);
-        if (overlap) AR_HIP(ctx, hipStreamWaitEvent(gs, ctx->ev_tile[set], 0));
         {
-            Stamper s(ctx, K_SETUP, gs);
-            k_setup<<<fp.n_groups, kSetupThreads, 0, gs>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_flat, ctx->d_records[set],
+            Stamper s(ctx, K_SETUP, fs);
+            k_setup<<<fp.n_groups, kSetupThreads, 0, fs>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_flat, ctx->d_records[set],
                                                          ctx->d_surv[set], ctx->d_surv_count[set], dircount);
         }
         {
-            Stamper s(ctx, K_BINSCAN, gs);
-            k_binscan<<<dim3(unsigned((nbins + 63) / 64), 16), 1024, 0, gs>>>(fp, dircount, blocksum);
+            Stamper s(ctx, K_BINSCAN, fs);
+            k_binscan<<<dim3(unsigned((nbins + 63) / 64), 16), 1024, 0, fs>>>(fp, dircount, blocksum);
         }
         {
-            Stamper s(ctx, K_BINOFF, gs);
-            k_binoffsets<<<1, 1024, 0, gs>>>(fp, blocksum, boff, ctx->d_state, ctx->pool_cap);
+            Stamper s(ctx, K_BINOFF, fs);
+            k_binoffsets<<<1, 1024, 0, fs>>>(fp, blocksum, boff, ctx->d_state, ctx->pool_cap);
         }
         {
-            Stamper s(ctx, K_FILL, gs);
-            k_fill<<<fp.n_groups, kSetupThreads, 0, gs>>>(fp, ctx->d_records[set], ctx->d_surv[set], ctx->d_surv_count[set], dircount, boff,
+            Stamper s(ctx, K_FILL, fs);
+            k_fill<<<fp.n_groups, kSetupThreads, 0, fs>>>(fp, ctx->d_records[set], ctx->d_surv[set], ctx->d_surv_count[set], dircount, boff,
                                                         ctx->d_state, ctx->d_entries[set], ctx->pool_cap, ctx->d_vis[set]);
         }
-        if (overlap) {
-            AR_HIP(ctx, hipEventRecord(ctx->ev_fill[set], gs));
-            AR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fill[set], 0));
-            AR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_ascii[set], 0));  // ridx[set] was read by frame f-2's smoothing
-            if (fp.mode_on != 1)  // k_tile writes the ASCII plane itself: not before the previous frame's smoothing has
-                AR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_ascii[set ^ 1], 0));
-        }
         {
-            Stamper s(ctx, K_TILE);
-            k_tile<<<unsigned((nbins + 7) / 8 * 8) << (2 * fp.bshift), 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_tripos, ctx->tripos_stride,
-                                                         ctx->d_records[set], ctx->d_entries[set], ctx->pool_cap, ctx->d_state,
-                                                         ctx->d_vis[set], ctx->d_rgba, ctx->d_depth, ascii_out, ctx->d_ridx[set],
-                                                         ctx->d_ids);
+            Stamper s(ctx, K_TILE, fs);
+            k_tile<<<unsigned((nbins + 7) / 8 * 8) << (2 * fp.bshift), 256, 0, fs>>>(
+                fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_tripos, ctx->tripos_stride, ctx->d_records[set], ctx->d_entries[set],
+                ctx->pool_cap, ctx->d_state, ctx->d_vis[set], ctx->d_rgba[oset], ctx->d_depth[oset], ascii_out, ctx->d_ridx[set],
+                ctx->d_ids[oset]);
         }
-        if (overlap) AR_HIP(ctx, hipEventRecord(ctx->ev_tile[set], ctx->stream));
         ctx->frame++;
     } else {
         {
@@ -1637,27 +1634,19 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
         }
         {
             Stamper s(ctx, K_SHADE);
-            k_shade<<<cell_blocks, 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_vis[0], ctx->d_rgba, ctx->d_depth,
-                                                         ascii_out, ctx->d_ridx[0], ctx->d_ids, ctx->d_counters);
+            k_shade<<<cell_blocks, 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_vis[0], ctx->d_rgba[0], ctx->d_depth[0],
+                                                         ascii_out, ctx->d_ridx[0], ctx->d_ids[0], ctx->d_counters);
         }
     }
     if (fp.mode_on == 1) {
-        if (tiled && overlap) {
-            AR_HIP(ctx, hipStreamWaitEvent(ctx->astream, ctx->ev_tile[set], 0));
-            {
-                Stamper s(ctx, K_ASCII, ctx->astream);
-                launch_ascii<false>(fp, ctx->d_ridx[set], ascii_out, ctx->astream);
-            }
-            AR_HIP(ctx, hipEventRecord(ctx->ev_ascii[set], ctx->astream));
-        } else {
-            Stamper s(ctx, K_ASCII);
-            launch_ascii<false>(fp, ctx->d_ridx[tiled ? set : 0], ascii_out, ctx->stream);
-        }
+        Stamper s(ctx, K_ASCII, fs);
+        launch_ascii<false>(fp, ctx->d_ridx[tiled ? set : 0], ascii_out, fs);
     }
     AR_HIP(ctx, hipGetLastError());
     ctx->vis_clean = true;
     ctx->rendered = true;
     ctx->last_tiled = tiled;
+    ctx->last_oset = oset;
     return 0;
 }
 
@@ -1674,24 +1663,16 @@ ar_ctx *ar_create(int device_id) {
     if (!ctx) { fail(nullptr, AR_E_NOMEM, "out of host memory"); return nullptr; }
     ctx->device = device_id;
     bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) == hipSuccess &&
-              (ctx->stream = ctx->own_stream) != nullptr &&
-              hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&ctx->astream, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->ev_out[0], hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->ev_out[1], hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->ev_ext, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->ev_ascii[0], hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->ev_ascii[1], hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->ev_fill[0], hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->ev_fill[1], hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->ev_tile[0], hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&ctx->ev_tile[1], hipEventDisableTiming) == hipSuccess &&
+              (ctx->stream = ctx->own_stream) != nullptr && hipEventCreateWithFlags(&ctx->ev_ext, hipEventDisableTiming) == hipSuccess &&
               hipMalloc(&ctx->d_medium, size_t(kMediumCapacity) * sizeof(TriRec)) == hipSuccess &&
               hipMalloc(&ctx->d_large, size_t(kLargeCapacity) * sizeof(TriRec)) == hipSuccess &&
               hipMalloc(&ctx->d_counters, 4 * sizeof(uint32_t)) == hipSuccess &&
               hipMemset(ctx->d_counters, 0, 4 * sizeof(uint32_t)) == hipSuccess &&
-              hipMalloc(&ctx->d_state, 2 * sizeof(BinState)) == hipSuccess &&
-              hipMemset(ctx->d_state, 0, 2 * sizeof(BinState)) == hipSuccess;
+              hipMalloc(&ctx->d_state, kSets * sizeof(BinState)) == hipSuccess &&
+              hipMemset(ctx->d_state, 0, kSets * sizeof(BinState)) == hipSuccess;
+    ctx->fstream[0] = ctx->own_stream;
+    for (int k = 1; ok && k < kSets; k++) ok = hipStreamCreateWithFlags(&ctx->fstream[k], hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; ok && k <= kSets; k++) ok = hipEventCreateWithFlags(&ctx->ev_out[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         fail(nullptr, AR_E_HIP, "context setup failed: %s", hipGetErrorString(hipGetLastError()));
         ar_destroy(ctx);
@@ -1711,9 +1692,9 @@ ar_ctx *ar_create(int device_id) {
 void ar_destroy(ar_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->gstream) (void)hipStreamSynchronize(ctx->gstream);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->astream) (void)hipStreamSynchronize(ctx->astream);
+    for (int k = 0; k < kSets; k++)
+        if (ctx->fstream[k]) (void)hipStreamSynchronize(ctx->fstream[k]);
+    if (ctx->stream && ctx->stream != ctx->own_stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &s : ctx->stamps) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
     free_targets(ctx);
@@ -1722,17 +1703,15 @@ void ar_destroy(ar_ctx *ctx) {
     (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii); (void)hipFree(ctx->d_q_colors);
     (void)hipFree(ctx->d_p_atlas); (void)hipFree(ctx->d_p_cov); (void)hipFree(ctx->d_p_image);
     (void)hipFree(ctx->d_state); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr); (void)hipFree(ctx->d_flat);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < kSets; k++) {
         (void)hipFree(ctx->d_entries[k]); (void)hipFree(ctx->d_surv[k]); (void)hipFree(ctx->d_surv_count[k]);
         (void)hipFree(ctx->d_dircount[k]); (void)hipFree(ctx->d_records[k]);
-        if (ctx->ev_fill[k]) (void)hipEventDestroy(ctx->ev_fill[k]);
-        if (ctx->ev_tile[k]) (void)hipEventDestroy(ctx->ev_tile[k]);
-        if (ctx->ev_ascii[k]) (void)hipEventDestroy(ctx->ev_ascii[k]);
-        if (ctx->ev_out[k]) (void)hipEventDestroy(ctx->ev_out[k]);
     }
+    for (int k = 0; k <= kSets; k++)
+        if (ctx->ev_out[k]) (void)hipEventDestroy(ctx->ev_out[k]);
     if (ctx->ev_ext) (void)hipEventDestroy(ctx->ev_ext);
-    if (ctx->gstream) (void)hipStreamDestroy(ctx->gstream);
-    if (ctx->astream) (void)hipStreamDestroy(ctx->astream);
+    for (int k = 1; k < kSets; k++)
+        if (ctx->fstream[k]) (void)hipStreamDestroy(ctx->fstream[k]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -1761,7 +1740,7 @@ int ar_set_mesh(ar_ctx *ctx, const float *vbo9, uint32_t n_verts, const uint32_t
     ctx->tripos_stride = (size_t(n_tris) + 63) / 64 * 64;
     AR_HIP(ctx, hipMalloc(&ctx->d_tripos, 9 * ctx->tripos_stride * sizeof(float)));
     AR_HIP(ctx, hipMalloc(&ctx->d_triattr, size_t(n_tris) * 24 * sizeof(float)));
-    for (int k = 0; k < 2; k++) AR_HIP(ctx, hipMalloc(&ctx->d_records[k], 2 * size_t(n_tris) * sizeof(BinRec)));
+    for (int k = 0; k < kSets; k++) AR_HIP(ctx, hipMalloc(&ctx->d_records[k], 2 * size_t(n_tris) * sizeof(BinRec)));
     AR_HIP(ctx, hipMalloc(&ctx->d_flat, size_t(n_tris)));
     k_tristream<<<(n_tris + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_vbo, ctx->d_idx, n_verts, n_tris, ctx->tripos_stride, ctx->d_tripos,
                                                               ctx->d_triattr, ctx->d_flat);
@@ -1832,12 +1811,13 @@ int ar_read(ar_ctx *ctx, uint8_t *rgba, float *depth, uint8_t *ascii, uint32_t *
     int rc = sync_streams(ctx);
     if (rc) return rc;
     const size_t n = size_t(ctx->cols) * ctx->rows;
-    if (rgba) AR_HIP(ctx, hipMemcpy(rgba, ctx->d_rgba, n * 4, hipMemcpyDeviceToHost));
-    if (depth) AR_HIP(ctx, hipMemcpy(depth, ctx->d_depth, n * sizeof(float), hipMemcpyDeviceToHost));
-    if (ascii) AR_HIP(ctx, hipMemcpy(ascii, ctx->d_ascii, n, hipMemcpyDeviceToHost));
+    const int o = ctx->last_oset;
+    if (rgba) AR_HIP(ctx, hipMemcpy(rgba, ctx->d_rgba[o], n * 4, hipMemcpyDeviceToHost));
+    if (depth) AR_HIP(ctx, hipMemcpy(depth, ctx->d_depth[o], n * sizeof(float), hipMemcpyDeviceToHost));
+    if (ascii) AR_HIP(ctx, hipMemcpy(ascii, ctx->d_ascii[o], n, hipMemcpyDeviceToHost));
     if (ids) {
-        if (!ctx->d_ids) return fail(ctx, AR_E_STATE, "ar_read: ids wanted but ar_set_id_output was not on for the last frame");
-        AR_HIP(ctx, hipMemcpy(ids, ctx->d_ids, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (!ctx->d_ids[o]) return fail(ctx, AR_E_STATE, "ar_read: ids wanted but ar_set_id_output was not on for the last frame");
+        AR_HIP(ctx, hipMemcpy(ids, ctx->d_ids[o], n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     return 0;
 }
@@ -1853,9 +1833,9 @@ int ar_render(ar_ctx *ctx, int cols, int rows, uint8_t *rgba, float *depth, uint
 void *ar_device_buffer(ar_ctx *ctx, int which) {
     if (!ctx) return nullptr;
     switch (which) {
-        case 0: return ctx->d_rgba;
-        case 1: return ctx->d_depth;
-        case 2: return ctx->d_ascii;
+        case 0: return ctx->d_rgba[ctx->last_oset];
+        case 1: return ctx->d_depth[ctx->last_oset];
+        case 2: return ctx->d_ascii[ctx->last_oset];
         default: return nullptr;
     }
 }
@@ -1898,10 +1878,14 @@ int ar_stream_wait_frame(ar_ctx *ctx, void *hip_stream) {
     if (!ctx) return AR_E_ARG;
     AR_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    AR_HIP(ctx, hipEventRecord(ctx->ev_out[0], ctx->stream));
-    AR_HIP(ctx, hipEventRecord(ctx->ev_out[1], ctx->astream));
-    AR_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_out[0], 0));
-    AR_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_out[1], 0));
+    for (int k = 0; k < kSets; k++) {
+        AR_HIP(ctx, hipEventRecord(ctx->ev_out[k], ctx->fstream[k]));
+        AR_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_out[k], 0));
+    }
+    if (ctx->stream != ctx->own_stream && ctx->stream != s) {
+        AR_HIP(ctx, hipEventRecord(ctx->ev_out[kSets], ctx->stream));
+        AR_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_out[kSets], 0));
+    }
     return 0;
 }
 
@@ -1909,9 +1893,8 @@ int ar_frame_wait_stream(ar_ctx *ctx, void *hip_stream) {
     if (!ctx) return AR_E_ARG;
     AR_HIP(ctx, hipSetDevice(ctx->device));
     AR_HIP(ctx, hipEventRecord(ctx->ev_ext, static_cast<hipStream_t>(hip_stream)));
-    // the output buffers are written on the pixel stream (tiles) and the ASCII stream (smoothing)
-    AR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_ext, 0));
-    AR_HIP(ctx, hipStreamWaitEvent(ctx->astream, ctx->ev_ext, 0));
+    for (int k = 0; k < kSets; k++) AR_HIP(ctx, hipStreamWaitEvent(ctx->fstream[k], ctx->ev_ext, 0));
+    if (ctx->stream != ctx->own_stream) AR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_ext, 0));
     return 0;
 }
 
@@ -2063,7 +2046,7 @@ int ar_read_colors(ar_ctx *ctx, int steps, int grayscale, uint32_t *colors) {
     AR_HIP(ctx, hipSetDevice(ctx->device));
     int rc = sync_streams(ctx);
     if (rc) return rc;
-    return colors_from_device(ctx, ctx->d_rgba, size_t(ctx->cols) * ctx->rows, steps, grayscale, colors);
+    return colors_from_device(ctx, ctx->d_rgba[ctx->last_oset], size_t(ctx->cols) * ctx->rows, steps, grayscale, colors);
 }
 
 int ar_set_id_output(ar_ctx *ctx, int on) {
@@ -2108,7 +2091,7 @@ int ar_frame_counters(ar_ctx *ctx, uint32_t out[8]) {
     if (rc) return rc;
     uint32_t c[4] = {0, 0, 0, 0}, last[2] = {0, 0};  // last: {overflow, n_entries} of the last tiled frame
     AR_HIP(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
-    AR_HIP(ctx, hipMemcpy(last, &ctx->d_state[(ctx->frame + 1u) & 1u].overflow, sizeof last, hipMemcpyDeviceToHost));
+    AR_HIP(ctx, hipMemcpy(last, &ctx->d_state[(ctx->frame + unsigned(kSets) - 1u) % unsigned(kSets)].overflow, sizeof last, hipMemcpyDeviceToHost));
     for (int k = 0; k < 8; k++) out[k] = 0;
     out[0] = ctx->n_tris;
     out[1] = ctx->last_tiled ? 0 : c[2];

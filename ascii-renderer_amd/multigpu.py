@@ -25,7 +25,8 @@ class _DeviceArray:
 
 
 def device_strip_tensor(renderer, cols, rows, row0, row1):
-    """uint8 tensor [row1-row0, cols] aliasing the renderer's ASCII output rows in HBM (no copy)."""
+    """uint8 tensor [row1-row0, cols] aliasing the ASCII output rows of the renderer's most recent frame in
+    HBM (no copy).  Overlapping frames alternate between buffer sets: take the alias after the frame."""
     base = renderer.device_buffer("ascii")
     if not base:
         raise RuntimeError("render one frame before asking for the device buffer")

@@ -2,6 +2,8 @@
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ar = importlib.import_module("ascii-renderer_amd")
+if os.environ.get("AR_LIB"):
+    ar.binding.LIB_PATH = os.environ["AR_LIB"]
 tris = int(os.environ.get("AR_TRIS", "1000")); cols, rows = 1920, 1080
 sc = ar.scenes.random_scene(tris, cols, rows)
 R = ar.Renderer(0)

@@ -224,10 +224,9 @@ def test_callers_stream_ascii_target_and_stream_handover(pkg, oracle):
         # (2) own streams, hand-over to the caller's stream and back
         r.set_camera(want[0][0], want[0][1])
         r.render_async(cols, rows)
-        r.sync()
-        local = mg.device_strip_tensor(r, cols, rows, 0, rows)
         r.set_camera(want[1][0], want[1][1])
         r.render_async(cols, rows)
+        local = mg.device_strip_tensor(r, cols, rows, 0, rows)      # buffers of the frame just enqueued
         r.stream_wait_frame(st.cuda_stream)
         with torch.cuda.stream(st):
             snap = local.clone()
