@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__re
 // Everything a frame writes exists kSets times, so that consecutive frames can overlap: see
 // enqueue_frame.
 // ------------------------------------------------------------------------------------------------
-constexpr int kSets = 2;               // frames in flight: every per-frame buffer exists kSets times
+constexpr int kSets = 3;               // frames in flight: every per-frame buffer exists kSets times
 constexpr int kTileW = 64, kTileH = 32, kTileCells = kTileW * kTileH;
 constexpr int kMaxTiles = 8000;       // tiles per frame the tiled path accepts
 constexpr int kMaxBins = 2048;        // >= kMaxTiles / 4 for any tile-grid shape the path accepts
