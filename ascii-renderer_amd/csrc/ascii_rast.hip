@@ -809,6 +809,66 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Bi
     }
 }
 
+// Colour of cell (i, j) for a record the near plane cut.  The record holds the sub-triangle's screen
+// vertices, so only the varyings of its three vertices are missing: each is a mesh vertex or the point
+// I + (O - I) * (dI / (dI - dO)) on the edge from an inside vertex I to an outside vertex O, exactly as
+// clip_near builds them.  Which is which follows from the signs of d = z_c + w_c of the three mesh
+// vertices; the varyings are then rebuilt and interpolated one component at a time, which keeps this
+// rarely taken path from setting the register budget of the kernel that contains it.
+__device__ __forceinline__ void shade_clipped_record(const FrameParams &fp, const float *__restrict__ vbo,
+                                                     const uint32_t *__restrict__ idx, const BinRec &rec, int i, int j,
+                                                     uint8_t (&px)[4]) {
+    const uint32_t t = rec.id >> 1, sub = rec.id & 1u;
+    const float *vp[3];
+    float d[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        vp[k] = vbo + size_t(idx[3 * size_t(t) + k]) * 9;
+        const float x = vp[k][0], y = vp[k][1], z = vp[k][2];
+        const float cz = ((fp.pv[2] * x + fp.pv[6] * y) + fp.pv[10] * z) + fp.pv[14];
+        const float cw = ((fp.pv[3] * x + fp.pv[7] * y) + fp.pv[11] * z) + fp.pv[15];
+        d[k] = cz + cw;
+    }
+    const bool in0 = d[0] >= 0.0f, in1 = d[1] >= 0.0f, in2 = d[2] >= 0.0f;
+    const int n_in = int(in0) + int(in1) + int(in2);
+    // A = the odd vertex out (the only inside one, or the only outside one), B and C follow it in winding order
+    const int a = (n_in == 1) ? (in0 ? 0 : (in1 ? 1 : 2)) : (!in0 ? 0 : (!in1 ? 1 : 2));
+    const int b = (a + 1) % 3, c = (a + 2) % 3;
+    // sub-triangle vertex m = mesh vertex I[m], or the point on the edge I[m] -> O[m] when O[m] >= 0
+    int I[3], O[3];
+    if (n_in == 1) { I[0] = a; O[0] = -1; I[1] = a; O[1] = b; I[2] = a; O[2] = c; }
+    else if (sub == 0u) { I[0] = b; O[0] = a; I[1] = b; O[1] = -1; I[2] = c; O[2] = -1; }
+    else { I[0] = b; O[0] = a; I[1] = c; O[1] = -1; I[2] = c; O[2] = a; }
+    float tt[3];
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+        const float dI = I[m] == 0 ? d[0] : (I[m] == 1 ? d[1] : d[2]);
+        const float dO = O[m] == 0 ? d[0] : (O[m] == 1 ? d[1] : d[2]);
+        tt[m] = dI / (dI - dO);
+    }
+    Edges e;
+    edges_from_screen(rec, e);
+    const double pxd = double(i) + 0.5, pyd = double(j) + 0.5;
+    float f[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) f[k] = float(e.a[k] * pxd + (e.b[k] * pyd + e.c[k]));
+    const float rS = 1.0f / ((f[0] + f[1]) + f[2]);
+    const float b0 = f[0] * rS, b1 = f[1] * rS, b2 = f[2] * rS;
+    float v[9];
+    for (int q = 0; q < 9; q++) {
+        const float o0 = vp[0][q], o1 = vp[1][q], o2 = vp[2][q];
+        float sv[3];
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            const float vi = I[m] == 0 ? o0 : (I[m] == 1 ? o1 : o2);
+            const float vo = O[m] == 0 ? o0 : (O[m] == 1 ? o1 : o2);
+            sv[m] = O[m] < 0 ? vi : vi + (vo - vi) * tt[m];
+        }
+        v[q] = (b0 * sv[0] + b1 * sv[1]) + b2 * sv[2];
+    }
+    shade(fp, v, px);
+}
+
 // Colour and depth of cell (i, j) from the winner's setup record; unclipped records take normal and
 // colour from the triangle's attribute row (one vertex's worth when the triangle is flat) and world
 // positions from the position planes (only when point lights are on); clipped ones are rebuilt by
@@ -817,7 +877,7 @@ __device__ __forceinline__ void shade_from_record(const FrameParams &fp, const f
                                                   const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
                                                   const float *__restrict__ tripos, size_t stride, const BinRec &rec,
                                                   int i, int j, uint8_t (&px)[4], float &zw) {
-    if (rec.flags & kFlagClipped) { shade_cell(fp, vbo, idx, rec.id, i, j, px, zw); return; }
+    if (rec.flags & kFlagClipped) { shade_clipped_record(fp, vbo, idx, rec, i, j, px); return; }  // zw: the key's
     const uint32_t t = rec.id >> 1;
     const float4 *row = reinterpret_cast<const float4 *>(triattr) + size_t(t) * 6;
     const int o1 = (rec.flags & kFlagFlat) ? 0 : 2, o2 = (rec.flags & kFlagFlat) ? 0 : 4;
@@ -1040,7 +1100,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
         const int rr = tr0 + (c >> 6), i = tx0 + (c & 63);
         const BinRec rec = records[uint32_t(keys[c])];  // the key's low word is the winner's record slot
         uint8_t px[4];
-        float zw;
+        float zw = __uint_as_float(uint32_t(keys[c] >> 32));  // the depth the raster pass computed from this record
         shade_from_record(fp, vbo, idx, triattr, tripos, stride, rec, i, fp.rows - 1 - rr, px, zw);
         if (fp.want_ids) ids[size_t(rr) * fp.cols + i] = rec.id;
         keys[c] = (uint64_t(__float_as_uint(zw)) << 32) |
