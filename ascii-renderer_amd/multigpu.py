@@ -51,7 +51,10 @@ class StripBatcher:
 
     `device` tensors live wherever the bands live (HBM with RCCL, host memory with gloo in the tests)."""
 
-    def __init__(self, band_rows, cols, batch, device):
+    def __init__(self, band_rows, cols, batch, device, before_gather=None, after_gather=None):
+        """before_gather / after_gather: called around each all-gather, e.g. to make the gathering stream
+        wait for the frames that filled the ring and the next frames wait for the gather (stream-ordered)."""
+        self.before_gather, self.after_gather = before_gather, after_gather
         self.world = dist.get_world_size()
         self.batch, self.h, self.cols = int(batch), int(band_rows), int(cols)
         self.ring = torch.empty((self.batch, self.h, self.cols), dtype=torch.uint8, device=device)
@@ -79,7 +82,11 @@ class StripBatcher:
     def flush(self):
         if self.filled == 0:
             return
+        if self.before_gather:
+            self.before_gather()
         dist.all_gather_into_tensor(self.out.view(-1), self.ring.view(-1))
+        if self.after_gather:
+            self.after_gather()
         self.gathered, self.filled = self.filled, 0
 
     def frame(self, k):

@@ -85,16 +85,17 @@ def main():
     row0, row1 = mg.strip_bounds(args.rows, world, rank)
     if gather:
         R.set_strip(row0, row1)
-        batcher = mg.StripBatcher(row1 - row0, args.cols, max(1, args.gather_batch), "cuda")
+        torch.cuda.set_stream(torch.cuda.Stream())         # a real stream handle (the default stream's is 0)
+        ts = torch.cuda.current_stream().cuda_stream
+        # the gather waits (on its stream) for the frames that filled the ring, the frames after it wait for
+        # the gather before they write the ring again: two stream-ordered hand-overs per batch, no host waits
+        batcher = mg.StripBatcher(row1 - row0, args.cols, max(1, args.gather_batch), "cuda",
+                                  before_gather=lambda: R.stream_wait_frame(ts), after_gather=lambda: R.frame_wait_stream(ts))
     R.render_async(args.cols, args.rows)
     R.sync()
-    if gather:
-        # Everything of a rank goes on torch's current stream, which RCCL orders itself against: the
-        # renderer's kernels write the strip straight into a slot of the batch ring, and every
-        # --gather-batch frames one all-gather combines the ranks' rings.  No host waits, no cross-stream
-        # events (each costs the host several microseconds, as much as a kernel launch).
-        torch.cuda.set_stream(torch.cuda.Stream())         # a real stream handle (the default stream's is 0)
-        R.set_stream(torch.cuda.current_stream().cuda_stream)
+    # Multi-GPU loop: frames overlap on the renderer's own streams (three in flight) and write their ASCII
+    # strip straight into a slot of the batch ring; every --gather-batch frames ONE RCCL all-gather combines
+    # the ranks' rings.  Per frame the host only launches the frame's kernels.
 
     def step():
         if not gather:
