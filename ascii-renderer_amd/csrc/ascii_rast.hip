@@ -476,7 +476,8 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__re
 // enqueue_frame.
 // ------------------------------------------------------------------------------------------------
 constexpr int kSets = 3;               // frames in flight: every per-frame buffer exists kSets times
-constexpr int kTileW = 64, kTileH = 32, kTileCells = kTileW * kTileH;
+constexpr int kTileShiftH = 5;          // log2 of the tile height
+constexpr int kTileW = 64, kTileH = 1 << kTileShiftH, kTileCells = kTileW * kTileH;  // (a tile is one wavefront wide)
 constexpr int kMaxTiles = 8000;       // tiles per frame the tiled path accepts
 constexpr int kMaxBins = 2048;        // >= kMaxTiles / 4 for any tile-grid shape the path accepts
 constexpr int kSetupThreads = 256;    // k_setup / k_fill workgroup size
@@ -577,7 +578,7 @@ __device__ __forceinline__ Vert<0> transform_position(const FrameParams &fp, flo
 __device__ __forceinline__ void bin_range(const FrameParams &fp, int i0, int i1, int j0, int j1, int &bx0, int &bx1,
                                           int &by0, int &by1) {
     bx0 = i0 >> (6 + fp.bshift); bx1 = i1 >> (6 + fp.bshift);
-    by0 = (fp.rows - 1 - j1 - fp.ya) >> (5 + fp.bshift); by1 = (fp.rows - 1 - j0 - fp.ya) >> (5 + fp.bshift);
+    by0 = (fp.rows - 1 - j1 - fp.ya) >> (kTileShiftH + fp.bshift); by1 = (fp.rows - 1 - j0 - fp.ya) >> (kTileShiftH + fp.bshift);
 }
 
 // One sub-triangle that survived setup: screen-space vertices and inclusive cell range.
@@ -778,7 +779,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Bi
         const uint4 sv = surv[loc];
         const int i0 = int(sv.y & 0xFFFFu), i1 = int(sv.y >> 16), j0 = int(sv.z & 0xFFFFu), j1 = int(sv.z >> 16);
         const int r0 = fp.rows - 1 - j1 - fp.ya, r1 = fp.rows - 1 - j0 - fp.ya;  // rows relative to the strip
-        const int tx0 = i0 >> 6, tx1 = i1 >> 6, ty0 = r0 >> 5, ty1 = r1 >> 5;
+        const int tx0 = i0 >> 6, tx1 = i1 >> 6, ty0 = r0 >> kTileShiftH, ty1 = r1 >> kTileShiftH;
         int bx0, bx1, by0, by1;
         bin_range(fp, i0, i1, j0, j1, bx0, bx1, by0, by1);
         bool direct = false;
