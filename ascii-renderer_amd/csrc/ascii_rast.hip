@@ -620,12 +620,12 @@ __device__ __forceinline__ BinRec make_record(const Candidate &c, uint32_t id, u
 // Workgroup g owns record slots [g * 2 * chunk, (g + 1) * 2 * chunk) and fills them densely, in
 // triangle order: a record's slot number ("loc") therefore grows with its id, and visibility keys
 // carry loc in place of the id - same tie-break, and the winner's record is found without a lookup.
-// surv: the same slots as (id, i0 | i1 << 16, j0 | j1 << 16, flags) tuples for k_fill.
+// surv: the cell ranges of the same slots, (i0 | i1 << 16, j0 | j1 << 16), all k_fill needs of a record.
 // One triangle per lane and pass; chunk is a multiple of the workgroup size (one pass up to about
 // four million triangles).
 __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const float *__restrict__ tripos, size_t stride,
                                                          const uint8_t *__restrict__ flat, BinRec *__restrict__ records,
-                                                         uint4 *__restrict__ surv, uint32_t *__restrict__ surv_count,
+                                                         uint2 *__restrict__ surv, uint32_t *__restrict__ surv_count,
                                                          uint32_t *__restrict__ dircount) {
     __shared__ uint32_t hist[kMaxBins];
     __shared__ uint32_t s_wave[kSetupThreads / 64];
@@ -662,8 +662,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const f
             const uint32_t loc = loc_base + slot;
             slot++;
             records[loc] = make_record(c[s], 2u * t + uint32_t(s), flags);
-            surv[loc] = make_uint4(2u * t + uint32_t(s), uint32_t(c[s].i0) | (uint32_t(c[s].i1) << 16),
-                                   uint32_t(c[s].j0) | (uint32_t(c[s].j1) << 16), flags);
+            surv[loc] = make_uint2(uint32_t(c[s].i0) | (uint32_t(c[s].i1) << 16), uint32_t(c[s].j0) | (uint32_t(c[s].j1) << 16));
             int bx0, bx1, by0, by1;
             bin_range(fp, c[s].i0, c[s].i1, c[s].j0, c[s].j1, bx0, bx1, by0, by1);
             for (int by = by0; by <= by1; by++)
@@ -750,7 +749,7 @@ __global__ __launch_bounds__(1024) void k_binoffsets(FrameParams fp, const uint3
 }
 
 __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const BinRec *__restrict__ records,
-                                                        const uint4 *__restrict__ surv,
+                                                        const uint2 *__restrict__ surv,
                                                         const uint32_t *__restrict__ surv_count,
                                                         const uint32_t *__restrict__ dircount,
                                                         const uint32_t *__restrict__ boff, const BinState *__restrict__ state,
@@ -776,8 +775,8 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Bi
     const uint32_t loc_base = blockIdx.x * 2u * fp.chunk;
     for (uint32_t s = tid; s < n; s += kSetupThreads) {
         const uint32_t loc = loc_base + s;  // record slot; also what the visibility keys carry
-        const uint4 sv = surv[loc];
-        const int i0 = int(sv.y & 0xFFFFu), i1 = int(sv.y >> 16), j0 = int(sv.z & 0xFFFFu), j1 = int(sv.z >> 16);
+        const uint2 sv = surv[loc];
+        const int i0 = int(sv.x & 0xFFFFu), i1 = int(sv.x >> 16), j0 = int(sv.y & 0xFFFFu), j1 = int(sv.y >> 16);
         const int r0 = fp.rows - 1 - j1 - fp.ya, r1 = fp.rows - 1 - j0 - fp.ya;  // rows relative to the strip
         const int tx0 = i0 >> 6, tx1 = i1 >> 6, ty0 = r0 >> kTileShiftH, ty1 = r1 >> kTileShiftH;
         int bx0, bx1, by0, by1;
@@ -1414,7 +1413,7 @@ struct ar_ctx {
     // everything the binning kernels write, per buffer set
     BinRec *d_records[kSets] = {};  // 2 x n_tris setup record slots, filled densely per k_setup workgroup
     uint8_t *d_flat = nullptr;       // n_tris flags: identical normal and colour at the three vertices
-    uint4 *d_surv[kSets] = {};  // per k_setup workgroup: (id, cell range, flags) of its surviving sub-triangles
+    uint2 *d_surv[kSets] = {};  // per k_setup workgroup: cell ranges of its surviving sub-triangles
     uint32_t *d_surv_count[kSets] = {};
     uint32_t *d_dircount[kSets] = {};  // per k_setup workgroup: entries per bin (+ scan scratch)
     size_t group_cap = 0, dircount_cap = 0;
@@ -1618,7 +1617,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
             }
             ctx->group_cap = 0;
             for (int k = 0; k < kSets; k++) {
-                AR_HIP(ctx, hipMalloc(&ctx->d_surv[k], want_groups * sizeof(uint4)));
+                AR_HIP(ctx, hipMalloc(&ctx->d_surv[k], want_groups * sizeof(uint2)));
                 AR_HIP(ctx, hipMalloc(&ctx->d_surv_count[k], (size_t(kMaxGroups) + 1) * sizeof(uint32_t)));
             }
             ctx->group_cap = want_groups;
