@@ -485,6 +485,8 @@ constexpr uint32_t kMaxGroups = 1024;  // k_setup workgroups (rows of the count 
 constexpr int kTileBigMax = 512;      // per-tile list of records swept cooperatively
 constexpr int kTileSmallCells = 64;   // cell-range area (inside the tile) one lane scans itself
 constexpr int kTileListMax = 2048;    // ids staged in LDS between the filter and the raster step
+constexpr int kEntryMaskShift = 28;   // a bin entry is (record slot) | (mask of the bin's 2x2 tiles) << 28
+constexpr uint32_t kEntryLocMask = (1u << kEntryMaskShift) - 1u;
 constexpr int kFilterBatch = 4;       // bin entries a k_tile lane loads per filter step
 constexpr uint32_t kFlagClipped = 1u; // record produced by the near-plane clip (vertices differ from the mesh's)
 constexpr uint32_t kFlagFlat = 2u;    // the triangle's three vertices carry identical normal and colour
@@ -753,7 +755,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Bi
                                                         const uint32_t *__restrict__ surv_count,
                                                         const uint32_t *__restrict__ dircount,
                                                         const uint32_t *__restrict__ boff, const BinState *__restrict__ state,
-                                                        unsigned long long *__restrict__ entries, uint32_t entries_cap,
+                                                        uint32_t *__restrict__ entries, uint32_t entries_cap,
                                                         uint64_t *__restrict__ vis) {
     __shared__ uint32_t base[kMaxBins], cnt[kMaxBins];
     __shared__ uint8_t fits[kMaxBins];
@@ -793,7 +795,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Bi
                 const uint32_t rowbits = ((1u << (ax1 + 1)) - 1u) & ~((1u << ax0) - 1u);
                 uint32_t m = 0;
                 for (int ay = ay0; ay <= ay1; ay++) m |= rowbits << (side * ay);
-                entries[size_t(base[b]) + atomicAdd(&cnt[b], 1u)] = (unsigned long long)loc | ((unsigned long long)m << 32);
+                entries[size_t(base[b]) + atomicAdd(&cnt[b], 1u)] = loc | (m << kEntryMaskShift);
             }
         if (direct) {  // a bin it touches has no room: resolve through the global key buffer
             Edges e;
@@ -985,7 +987,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
                                               const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
                                               const float *__restrict__ tripos, size_t stride,
                                               const BinRec *__restrict__ records,
-                                              const unsigned long long *__restrict__ entries, uint32_t entries_cap,
+                                              const uint32_t *__restrict__ entries, uint32_t entries_cap,
                                               const BinState *__restrict__ state, uint64_t *__restrict__ vis,
                                               uint8_t *__restrict__ rgba, float *__restrict__ depth,
                                               uint8_t *__restrict__ ascii, uint8_t *__restrict__ ridx,
@@ -1021,15 +1023,15 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
     // overflow on the next step (or at the end) rasterise what it holds
     // (kFilterBatch entries per lane and step, all loads in flight together: the step is one memory latency)
     for (uint32_t eb = e_begin;; eb += 256 * kFilterBatch) {
-        unsigned long long ent[kFilterBatch];
+        uint32_t ent[kFilterBatch];
 #pragma unroll
         for (int q = 0; q < kFilterBatch; q++) {
             const uint32_t e = eb + uint32_t(q) * 256u + tid;
-            ent[q] = e < e_end ? entries[e] : 0ull;  // mask 0 never matches
+            ent[q] = e < e_end ? entries[e] : 0u;  // mask 0 never matches
         }
 #pragma unroll
         for (int q = 0; q < kFilterBatch; q++)
-            if (uint32_t(ent[q] >> 32) & bit) list[atomicAdd(&n_list, 1u)] = uint32_t(ent[q]);
+            if ((ent[q] >> kEntryMaskShift) & bit) list[atomicAdd(&n_list, 1u)] = ent[q] & kEntryLocMask;
         __syncthreads();
         const uint32_t nl = n_list;
         const bool last = eb + 256 * kFilterBatch >= e_end;
@@ -1417,7 +1419,7 @@ struct ar_ctx {
     uint32_t *d_surv_count[kSets] = {};
     uint32_t *d_dircount[kSets] = {};  // per k_setup workgroup: entries per bin (+ scan scratch)
     size_t group_cap = 0, dircount_cap = 0;
-    unsigned long long *d_entries[kSets] = {};  // (record slot, tile mask) entries grouped by bin
+    uint32_t *d_entries[kSets] = {};  // (record slot, tile mask) entries grouped by bin
     uint32_t pool_cap = 0;
     BinState *d_state = nullptr;     // kSets blocks
     uint32_t frame = 0;              // tiled frames enqueued so far
@@ -1574,7 +1576,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
     const size_t nt = size_t(fp.ntx) * fp.nty;
     const size_t nbins = size_t(fp.nbx) * fp.nby;
     const bool tiled = ctx->path == 0 && nt <= size_t(kMaxTiles) && nbins <= size_t(kMaxBins) && cols <= 65535 &&
-                       rows <= 65535 && ctx->d_tripos;
+                       rows <= 65535 && ctx->d_tripos && ctx->n_tris <= (kEntryLocMask >> 1) - 65536u;  // slots fit an entry
     const int set = int(ctx->frame % unsigned(kSets));  // buffer set of this frame (tiled path)
     const bool overlap = tiled && may_overlap && !ctx->ext_stream && ctx->overlap != 0;
     if (!overlap && ctx->overlapped_in_flight) {  // frames still running on the frame streams
@@ -1604,7 +1606,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
             if (rc) return rc;
             for (int k = 0; k < kSets; k++) { (void)hipFree(ctx->d_entries[k]); ctx->d_entries[k] = nullptr; }
             ctx->pool_cap = 0;
-            for (int k = 0; k < kSets; k++) AR_HIP(ctx, hipMalloc(&ctx->d_entries[k], size_t(want_cap) * sizeof(unsigned long long)));
+            for (int k = 0; k < kSets; k++) AR_HIP(ctx, hipMalloc(&ctx->d_entries[k], size_t(want_cap) * sizeof(uint32_t)));
             ctx->pool_cap = want_cap;
         }
         const size_t want_groups = size_t(fp.n_groups) * 2 * chunk;
