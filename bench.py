@@ -45,8 +45,8 @@ def cpu_baseline(ar, sc, budget_s=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--tris", type=int, default=N_TRIS)
     ap.add_argument("--cols", type=int, default=COLS)
     ap.add_argument("--rows", type=int, default=ROWS)
@@ -162,7 +162,7 @@ def main():
             "k_setup": args.tris * 37,
             "k_tile": cells * 9,
             "k_ascii": cells * 2,                        # ramp index in, ASCII code out
-            "k_fill": counters["bin_records"] * 8,       # one 8-byte entry per (sub-triangle, bin)
+            "k_fill": counters["bin_records"] * 4,       # one 4-byte entry per (sub-triangle, bin)
             "k_binscan": 0, "k_binoffsets": 0,           # bookkeeping: no algorithmic traffic of their own
             # direct path: reference layout, 3 x 36 B vertices + 12 B indices per triangle
             "k_raster": args.tris * 120,
