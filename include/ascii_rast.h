@@ -85,7 +85,7 @@ int ar_read(ar_ctx *ctx, uint8_t *rgba, float *depth, uint8_t *ascii, uint32_t *
 
 /* Device addresses of the output buffers of the most recently enqueued frame: which = 0 rgba, 1 depth,
  * 2 ascii.  NULL before the first render.  While frames overlap (AR_OPT_OVERLAP) consecutive frames write
- * alternating sets of buffers, so ask again after each ar_render_async; with AR_OPT_OVERLAP 0, with
+ * different sets of buffers in rotation, so ask again after each ar_render_async; with AR_OPT_OVERLAP 0, with
  * ar_set_stream and for ar_render the addresses only change with the grid size. */
 void *ar_device_buffer(ar_ctx *ctx, int which);
 
@@ -167,10 +167,10 @@ int ar_frame_counters(ar_ctx *ctx, uint32_t out[8]);
  *   AR_OPT_PATH          0 (default): tile-binned path whenever the grid has at most 8000 tiles of
  *                        64x32 cells, else the direct path; 1: always the direct path (every
  *                        fragment resolved with a 64-bit atomic min in HBM).
- *   AR_OPT_OVERLAP       1 or 2 (default): consecutive ar_render_async frames of the tiled path run on
- *                        alternating streams of the context, each with its own set of buffers, so that two
- *                        frames share the GPU (no events between them); 0: one stream, frames strictly one
- *                        after the other.  ar_render (blocking) never overlaps.
+ *   AR_OPT_OVERLAP       1 or 2 (default): consecutive ar_render_async frames of the tiled path run on three
+ *                        streams of the context in rotation, each with its own set of buffers, so that up to
+ *                        three frames share the GPU (no events between them); 0: one stream, frames strictly
+ *                        one after the other.  ar_render (blocking) never overlaps.
  *   AR_OPT_POOL_RECORDS  capacity of the tiled path's (sub-triangle, bin) entry pool in entries;
  *                        0 (default) sizes it as 2 x triangles + 65536. */
 #define AR_OPT_PATH 1
