@@ -423,3 +423,46 @@ def test_randomised_sweep_against_oracle():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "250 cases, 0 mismatches" in r.stdout
+
+
+def test_two_contexts_interleaved_and_from_two_threads(pkg, oracle):
+    """Contexts share nothing: two renderers with different scenes, frames enqueued alternately without
+    waiting, then each driven from its own thread."""
+    import threading
+    a, b = pkg.Renderer(0), pkg.Renderer(0)
+    try:
+        sa = pkg.scenes.random_scene(120_000, 320, 200, mesh_grid=(320, 200))
+        sb = pkg.scenes.icosphere_scene(cols=333, rows=77, subdiv=4, point_lights=2)
+        want = {}
+        for name, sc in (("a", sa), ("b", sb)):
+            rgba, depth, _ = oracle.render(sc["vbo"], sc["idx"], sc["proj"], sc["view"], sc["lights"], sc["cols"], sc["rows"])
+            want[name] = (rgba, depth, oracle.quantize(rgba, sc["cols"], sc["rows"], pkg.scenes.DEFAULT_RAMP, 1, 2, 12))
+        pkg.scenes.upload(a, sa)
+        pkg.scenes.upload(b, sb)
+        for _ in range(7):
+            a.render_async(sa["cols"], sa["rows"])
+            b.render_async(sb["cols"], sb["rows"])
+        for r, name in ((a, "a"), (b, "b")):
+            out = r.read()
+            assert np.array_equal(out["rgba"], want[name][0]) and np.array_equal(out["ascii"], want[name][2]), name
+            assert np.array_equal(out["depth"].view(np.uint32), want[name][1].view(np.uint32)), name
+        errors = []
+
+        def drive(r, sc, name):
+            try:
+                for _ in range(20):
+                    out = r.render(sc["cols"], sc["rows"])
+                    if not (np.array_equal(out["rgba"], want[name][0]) and np.array_equal(out["ascii"], want[name][2])):
+                        errors.append(name)
+            except Exception as e:          # noqa: BLE001 - reported below
+                errors.append("%s: %r" % (name, e))
+
+        ts = [threading.Thread(target=drive, args=(a, sa, "a")), threading.Thread(target=drive, args=(b, sb, "b"))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errors, errors
+    finally:
+        a.close()
+        b.close()
