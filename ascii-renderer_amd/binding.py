@@ -15,7 +15,7 @@ EXPORTS = [
     "ar_set_ascii", "ar_set_strip", "ar_set_id_output", "ar_render", "ar_render_async", "ar_sync", "ar_read",
     "ar_device_buffer", "ar_stream", "ar_host_alloc", "ar_host_free", "ar_stream_wait_frame", "ar_frame_wait_stream", "ar_set_stream",
     "ar_set_ascii_target", "ar_quantize", "ar_quantize_colors", "ar_read_colors", "ar_present", "ar_set_profiling", "ar_kernel_stats",
-    "ar_frame_counters", "ar_set_option",
+    "ar_frame_counters", "ar_set_option", "ar_set_mesh_uv", "ar_set_texture",
 ]
 _lib = None
 
@@ -46,6 +46,8 @@ def load_library():
     L.ar_last_error.argtypes = [vp]
     L.ar_last_error.restype = ctypes.c_char_p
     L.ar_set_mesh.argtypes = [vp, _fp, ctypes.c_uint32, _u32p, ctypes.c_uint32]
+    L.ar_set_mesh_uv.argtypes = [vp, ctypes.POINTER(ctypes.c_uint16), ctypes.c_uint32]
+    L.ar_set_texture.argtypes = [vp, _u8p, ctypes.c_int, ctypes.c_int]
     L.ar_set_camera.argtypes = [vp, _fp, _fp]
     L.ar_set_lights.argtypes = [vp, _fp, _fp, _fp, ctypes.c_int, _fp, _fp]
     L.ar_set_ascii.argtypes = [vp, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -78,7 +80,7 @@ def load_library():
     L.ar_set_option.argtypes = [vp, ctypes.c_int, ctypes.c_longlong]
     for name in ("ar_set_id_output", "ar_set_mesh", "ar_set_camera", "ar_set_lights", "ar_set_ascii", "ar_set_strip", "ar_set_id_output", "ar_render",
                  "ar_render_async", "ar_sync", "ar_read", "ar_quantize", "ar_stream_wait_frame", "ar_frame_wait_stream", "ar_set_stream", "ar_set_ascii_target", "ar_quantize_colors", "ar_read_colors", "ar_present", "ar_set_profiling", "ar_kernel_stats",
-                 "ar_frame_counters", "ar_set_option"):
+                 "ar_frame_counters", "ar_set_option", "ar_set_mesh_uv", "ar_set_texture"):
         getattr(L, name).restype = ctypes.c_int
     _lib = L
     return L
@@ -120,6 +122,26 @@ class Renderer:
         if vbo.size % 9 or idx.size % 3:
             raise ValueError("vbo must hold 9 floats per vertex and idx 3 indices per triangle")
         self._check(self._L.ar_set_mesh(self._h, vp, vbo.size // 9, idx.ctypes.data_as(_u32p), idx.size // 3))
+
+    def set_mesh_uv(self, uv8):
+        """uv8: uint16 [n_tris, 8] rows (u0, v0, u1, v1, u2, v2, flags, 0) for the current mesh, or None to remove."""
+        if uv8 is None:
+            self._check(self._L.ar_set_mesh_uv(self._h, None, 0))
+            return
+        uv8 = np.ascontiguousarray(uv8, dtype=np.uint16)
+        if uv8.ndim != 2 or uv8.shape[1] != 8:
+            raise ValueError("uv8 must be [n_tris, 8]")
+        self._check(self._L.ar_set_mesh_uv(self._h, uv8.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), uv8.shape[0]))
+
+    def set_texture(self, atlas):
+        """atlas: uint8 [height, width, 4] as the reference hands it to texImage2D, or None to remove."""
+        if atlas is None:
+            self._check(self._L.ar_set_texture(self._h, None, 0, 0))
+            return
+        atlas = np.ascontiguousarray(atlas, dtype=np.uint8)
+        if atlas.ndim != 3 or atlas.shape[2] != 4:
+            raise ValueError("atlas must be [height, width, 4]")
+        self._check(self._L.ar_set_texture(self._h, atlas.ctypes.data_as(_u8p), atlas.shape[1], atlas.shape[0]))
 
     def set_camera(self, proj, view):
         _p, pp = _f32(proj)

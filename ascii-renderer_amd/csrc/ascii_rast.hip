@@ -63,6 +63,7 @@ struct FrameParams {
     uint32_t chunk, n_groups;  // triangles per k_setup workgroup, number of those workgroups
     uint32_t frame;  // frame counter
     int set;         // buffer set of this frame (frame % kSets): binning state block, record slots, ...
+    int tex_w, tex_h;  // atlas size in texels; 0 x 0 while texturing is off
     uint8_t ramp[AR_MAX_RAMP];
 };
 
@@ -93,7 +94,7 @@ __device__ __forceinline__ Vert<NV> load_vertex(const FrameParams &fp, const flo
     if (NV > 0) {
         o.v[0] = x; o.v[1] = y; o.v[2] = z;
 #pragma unroll
-        for (int k = 3; k < NV; k++) o.v[k] = p[k];
+        for (int k = 3; k < NV; k++) o.v[k] = k < 9 ? p[k] : 0.0f;  // beyond the buffer's nine: texel coordinates, set by the caller
     }
     return o;
 }
@@ -353,7 +354,7 @@ __device__ __forceinline__ int ramp_index(int r, int g, int b, int ramp_len) {
 }
 
 // raster_shader.js:42-62 in binary32.
-__device__ __forceinline__ void shade(const FrameParams &fp, const float (&v)[9], uint8_t (&out)[4]) {
+__device__ __forceinline__ void shade(const FrameParams &fp, const float *v, uint8_t (&out)[4]) {
     const float len2 = (v[3] * v[3] + v[4] * v[4]) + v[5] * v[5];
     const float inv = (len2 > 0.0f) ? 1.0f / sqrtf(len2) : 0.0f;
     const float N[3] = {v[3] * inv, v[4] * inv, v[5] * inv};
@@ -383,18 +384,54 @@ __device__ __forceinline__ void shade(const FrameParams &fp, const float (&v)[9]
     out[3] = 255;
 }
 
+// Atlas lookup of one fragment at interpolated texel coordinates (u, v) (shader_utils.js:108-117: nearest
+// texel floor(uv + 0.5), nothing outside the atlas; fetchAtlas :100-105 reads row height-1-y of the
+// uploaded array).  Texel classes as the reference's primary ray treats them (pathtrace_shader.js:141-152):
+// alpha 32..126 - the texel's RGB goes out unshaded with that alpha, an ASCII override for the
+// quantizer (returns true, px is final); alpha 1 - the texel's rgb / 255 replaces the colour varying;
+// anything else - untextured.
+__device__ __forceinline__ bool apply_texture(const FrameParams &fp, const uint32_t *__restrict__ atlas, float u, float v,
+                                              float *col, uint8_t (&px)[4]) {
+    const float tx = floorf(u + 0.5f), ty = floorf(v + 0.5f);
+    if (!(tx >= 0.0f) || !(ty >= 0.0f) || !(tx < float(fp.tex_w)) || !(ty < float(fp.tex_h))) return false;
+    const uint32_t q = atlas[size_t(fp.tex_h - 1 - int(ty)) * fp.tex_w + int(tx)];
+    const uint32_t a = q >> 24;
+    if (a >= 32u && a <= 126u) {
+        px[0] = uint8_t(q); px[1] = uint8_t(q >> 8); px[2] = uint8_t(q >> 16); px[3] = uint8_t(a);
+        return true;
+    }
+    if (a == 1u) {
+        col[0] = float(q & 255u) / 255.0f; col[1] = float((q >> 8) & 255u) / 255.0f; col[2] = float((q >> 16) & 255u) / 255.0f;
+    }
+    return false;
+}
+
+constexpr uint32_t kUvSample = 1u;  // flags word of a triangle's texel-coordinate row: sample the atlas
+
 // Colour and depth of cell (i, j) (GL window coordinates) for winner id = 2*triangle + sub: rebuild the
 // (sub-)triangle from the mesh with the varyings, evaluate the same edge expressions as the raster
 // pass (which reproduces its depth bit for bit), interpolate perspective-correctly and shade.
+// triuv: per triangle (u0 | v0 << 16, u1 | v1 << 16, u2 | v2 << 16, flags); read only while texturing is on.
 __device__ __forceinline__ void shade_cell(const FrameParams &fp, const float *__restrict__ vbo,
-                                           const uint32_t *__restrict__ idx, uint32_t id, int i, int j,
+                                           const uint32_t *__restrict__ idx, const uint4 *__restrict__ triuv,
+                                           const uint32_t *__restrict__ atlas, uint32_t id, int i, int j,
                                            uint8_t (&px)[4], float &zw) {
     const uint32_t t = id >> 1, sub = id & 1u;
     const uint32_t v0 = idx[3 * size_t(t)], v1 = idx[3 * size_t(t) + 1], v2 = idx[3 * size_t(t) + 2];
-    const Vert<9> in0 = load_vertex<9>(fp, vbo, v0), in1 = load_vertex<9>(fp, vbo, v1), in2 = load_vertex<9>(fp, vbo, v2);
-    Vert<9> s0[3], s1[3];
-    clip_near<9>(in0, in1, in2, s0, s1);
-    const Vert<9> t0 = sub ? s1[0] : s0[0], t1 = sub ? s1[1] : s0[1], t2 = sub ? s1[2] : s0[2];
+    Vert<11> in0 = load_vertex<11>(fp, vbo, v0), in1 = load_vertex<11>(fp, vbo, v1), in2 = load_vertex<11>(fp, vbo, v2);
+    bool textured = false;
+    if (fp.tex_w > 0) {
+        const uint4 uv = triuv[t];
+        textured = (uv.w & kUvSample) != 0u;
+        if (textured) {
+            in0.v[9] = float(uv.x & 0xFFFFu); in0.v[10] = float(uv.x >> 16);
+            in1.v[9] = float(uv.y & 0xFFFFu); in1.v[10] = float(uv.y >> 16);
+            in2.v[9] = float(uv.z & 0xFFFFu); in2.v[10] = float(uv.z >> 16);
+        }
+    }
+    Vert<11> s0[3], s1[3];
+    clip_near<11>(in0, in1, in2, s0, s1);
+    const Vert<11> t0 = sub ? s1[0] : s0[0], t1 = sub ? s1[1] : s0[1], t2 = sub ? s1[2] : s0[2];
     Screen sc;
     to_screen(t0.c, t1.c, t2.c, fp.hw, fp.hh, sc);
     Edges e;
@@ -403,9 +440,10 @@ __device__ __forceinline__ void shade_cell(const FrameParams &fp, const float *_
     cover(e, i, j, f, zw);
     const float rS = 1.0f / ((f[0] + f[1]) + f[2]);
     const float b0 = f[0] * rS, b1 = f[1] * rS, b2 = f[2] * rS;
-    float v[9];
+    float v[11];
 #pragma unroll
-    for (int q = 0; q < 9; q++) v[q] = (b0 * t0.v[q] + b1 * t1.v[q]) + b2 * t2.v[q];
+    for (int q = 0; q < 11; q++) v[q] = (b0 * t0.v[q] + b1 * t1.v[q]) + b2 * t2.v[q];
+    if (textured && apply_texture(fp, atlas, v[9], v[10], v + 6, px)) return;
     shade(fp, v, px);
 }
 
@@ -413,7 +451,8 @@ __device__ __forceinline__ void shade_cell(const FrameParams &fp, const float *_
 // The cell's visibility key is put back to "background" here, so the next frame needs no clear pass;
 // lane 0 of block 0 retires the frame's queue counters (cnt[0..1] live, cnt[2..3] = last frame).
 __global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__restrict__ vbo,
-                                               const uint32_t *__restrict__ idx, uint64_t *__restrict__ vis,
+                                               const uint32_t *__restrict__ idx, const uint4 *__restrict__ triuv,
+                                               const uint32_t *__restrict__ atlas, uint64_t *__restrict__ vis,
                                                uint8_t *__restrict__ rgba, float *__restrict__ depth,
                                                uint8_t *__restrict__ ascii, uint8_t *__restrict__ ridx,
                                                uint32_t *__restrict__ ids, uint32_t *__restrict__ cnt) {
@@ -432,7 +471,7 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__re
     float zw = 1.0f;
     if (key != kBackgroundKey) {
         vis[cell] = kBackgroundKey;
-        shade_cell(fp, vbo, idx, uint32_t(key), i, j, px, zw);
+        shade_cell(fp, vbo, idx, triuv, atlas, uint32_t(key), i, j, px, zw);
     }
     *reinterpret_cast<uint32_t *>(rgba + cell * 4) =
         uint32_t(px[0]) | (uint32_t(px[1]) << 8) | (uint32_t(px[2]) << 16) | (uint32_t(px[3]) << 24);
@@ -440,7 +479,7 @@ __global__ __launch_bounds__(256) void k_shade(FrameParams fp, const float *__re
     if (fp.want_ids) ids[cell] = uint32_t(key);
     const int ri = ramp_index(px[0], px[1], px[2], fp.ramp_len);
     if (fp.mode_on) ridx[cell] = uint8_t(ri);  // input of the smoothing pass
-    else if (r >= fp.row0 && r < fp.row1) ascii[cell] = fp.ramp[ri];
+    else if (r >= fp.row0 && r < fp.row1) ascii[cell] = (px[3] >= 2 && px[3] <= 254) ? px[3] : fp.ramp[ri];  // override: textured cells only
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -490,12 +529,13 @@ constexpr uint32_t kEntryLocMask = (1u << kEntryMaskShift) - 1u;
 constexpr int kFilterBatch = 4;       // bin entries a k_tile lane loads per filter step
 constexpr uint32_t kFlagClipped = 1u; // record produced by the near-plane clip (vertices differ from the mesh's)
 constexpr uint32_t kFlagFlat = 2u;    // the triangle's three vertices carry identical normal and colour
+constexpr uint32_t kFlagTextured = 4u;  // the triangle samples the atlas (set from its texel-coordinate row)
 
 struct __align__(16) BinRec {
     float X[3], Y[3], W[3], Z[3];
     uint32_t id;              // 2*triangle + sub-triangle
     uint16_t i0, i1, j0, j1;  // inclusive cell range, GL window rows (y up)
-    uint32_t flags;           // kFlagClipped | kFlagFlat
+    uint32_t flags;           // kFlagClipped | kFlagFlat | kFlagTextured
 };
 static_assert(sizeof(BinRec) == 64, "bin records are four 16-byte loads");
 
@@ -535,7 +575,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
 
 // Per triangle: positions -> planes pos[k*stride + t] (k = 3*vertex + axis); normal and colour of each
 // vertex -> attr[t*24 + 8*v ..] = (nx, ny, nz, r, g, b, 0, 0), so a vertex is one 16-byte plus one
-// 8-byte load; flat[t] = 1 when the three normals and the three colours are identical.
+// 8-byte load; flat[t] = kFlagFlat when the three normals and the three colours are identical.
 // A triangle that names a vertex outside the buffer gets NaN positions, which every later stage rejects.
 __global__ __launch_bounds__(256) void k_tristream(const float *__restrict__ vbo, const uint32_t *__restrict__ idx,
                                                    uint32_t n_verts, uint32_t n_tris, size_t stride,
@@ -565,7 +605,16 @@ __global__ __launch_bounds__(256) void k_tristream(const float *__restrict__ vbo
 #pragma unroll
         for (int q = 3; q < 9; q++) is_flat = is_flat && (__float_as_uint(a[v][q]) == __float_as_uint(a[0][q]));
     }
-    flat[t] = is_flat ? 1 : 0;
+    flat[t] = is_flat ? uint8_t(kFlagFlat) : uint8_t(0);
+}
+
+// Copies the "sample the atlas" bit of every triangle's texel-coordinate row into its flag byte (all bits
+// cleared when triuv is null).
+__global__ __launch_bounds__(256) void k_uvflags(const uint4 *__restrict__ triuv, uint32_t n_tris, uint8_t *__restrict__ flat) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_tris) return;
+    const bool sample = triuv && (triuv[t].w & kUvSample) != 0u;
+    flat[t] = uint8_t((flat[t] & ~kFlagTextured) | (sample ? kFlagTextured : 0u));
 }
 
 __device__ __forceinline__ Vert<0> transform_position(const FrameParams &fp, float x, float y, float z) {
@@ -651,7 +700,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const f
             float p[9];
 #pragma unroll
             for (int q = 0; q < 9; q++) p[q] = tripos[size_t(q) * stride + t];
-            flags = flat[t] ? kFlagFlat : 0u;
+            flags = flat[t];  // kFlagFlat | kFlagTextured
             triangle_setup(fp, p, jlo, jhi, c, have, clipped);
             if (clipped) flags |= kFlagClipped;
         }
@@ -818,7 +867,8 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Bi
 // vertices; the varyings are then rebuilt and interpolated one component at a time, which keeps this
 // rarely taken path from setting the register budget of the kernel that contains it.
 __device__ __forceinline__ void shade_clipped_record(const FrameParams &fp, const float *__restrict__ vbo,
-                                                     const uint32_t *__restrict__ idx, const BinRec &rec, int i, int j,
+                                                     const uint32_t *__restrict__ idx, const uint4 *__restrict__ triuv,
+                                                     const uint32_t *__restrict__ atlas, const BinRec &rec, int i, int j,
                                                      uint8_t (&px)[4]) {
     const uint32_t t = rec.id >> 1, sub = rec.id & 1u;
     const float *vp[3];
@@ -856,9 +906,8 @@ __device__ __forceinline__ void shade_clipped_record(const FrameParams &fp, cons
     for (int k = 0; k < 3; k++) f[k] = float(e.a[k] * pxd + (e.b[k] * pyd + e.c[k]));
     const float rS = 1.0f / ((f[0] + f[1]) + f[2]);
     const float b0 = f[0] * rS, b1 = f[1] * rS, b2 = f[2] * rS;
-    float v[9];
-    for (int q = 0; q < 9; q++) {
-        const float o0 = vp[0][q], o1 = vp[1][q], o2 = vp[2][q];
+    // one varying with values o0, o1, o2 at the mesh vertices, at this cell
+    auto varying = [&](float o0, float o1, float o2) {
         float sv[3];
 #pragma unroll
         for (int m = 0; m < 3; m++) {
@@ -866,7 +915,15 @@ __device__ __forceinline__ void shade_clipped_record(const FrameParams &fp, cons
             const float vo = O[m] == 0 ? o0 : (O[m] == 1 ? o1 : o2);
             sv[m] = O[m] < 0 ? vi : vi + (vo - vi) * tt[m];
         }
-        v[q] = (b0 * sv[0] + b1 * sv[1]) + b2 * sv[2];
+        return (b0 * sv[0] + b1 * sv[1]) + b2 * sv[2];
+    };
+    float v[9];
+    for (int q = 0; q < 9; q++) v[q] = varying(vp[0][q], vp[1][q], vp[2][q]);
+    if ((rec.flags & kFlagTextured) && fp.tex_w > 0) {
+        const uint4 uv = triuv[t];
+        const float tu = varying(float(uv.x & 0xFFFFu), float(uv.y & 0xFFFFu), float(uv.z & 0xFFFFu));
+        const float tv = varying(float(uv.x >> 16), float(uv.y >> 16), float(uv.z >> 16));
+        if (apply_texture(fp, atlas, tu, tv, v + 6, px)) return;
     }
     shade(fp, v, px);
 }
@@ -877,9 +934,10 @@ __device__ __forceinline__ void shade_clipped_record(const FrameParams &fp, cons
 // shade_cell.
 __device__ __forceinline__ void shade_from_record(const FrameParams &fp, const float *__restrict__ vbo,
                                                   const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
-                                                  const float *__restrict__ tripos, size_t stride, const BinRec &rec,
-                                                  int i, int j, uint8_t (&px)[4], float &zw) {
-    if (rec.flags & kFlagClipped) { shade_clipped_record(fp, vbo, idx, rec, i, j, px); return; }  // zw: the key's
+                                                  const float *__restrict__ tripos, size_t stride,
+                                                  const uint4 *__restrict__ triuv, const uint32_t *__restrict__ atlas,
+                                                  const BinRec &rec, int i, int j, uint8_t (&px)[4], float &zw) {
+    if (rec.flags & kFlagClipped) { shade_clipped_record(fp, vbo, idx, triuv, atlas, rec, i, j, px); return; }  // zw: the key's
     const uint32_t t = rec.id >> 1;
     const float4 *row = reinterpret_cast<const float4 *>(triattr) + size_t(t) * 6;
     const int o1 = (rec.flags & kFlagFlat) ? 0 : 2, o2 = (rec.flags & kFlagFlat) ? 0 : 4;
@@ -907,6 +965,12 @@ __device__ __forceinline__ void shade_from_record(const FrameParams &fp, const f
         for (int q = 0; q < 3; q++) v[q] = (b0 * p[q] + b1 * p[3 + q]) + b2 * p[6 + q];
     } else {
         v[0] = v[1] = v[2] = 0.0f;  // only the point-light loop reads the position
+    }
+    if ((rec.flags & kFlagTextured) && fp.tex_w > 0) {
+        const uint4 uv = triuv[t];
+        const float tu = (b0 * float(uv.x & 0xFFFFu) + b1 * float(uv.y & 0xFFFFu)) + b2 * float(uv.z & 0xFFFFu);
+        const float tv = (b0 * float(uv.x >> 16) + b1 * float(uv.y >> 16)) + b2 * float(uv.z >> 16);
+        if (apply_texture(fp, atlas, tu, tv, v + 6, px)) return;
     }
     shade(fp, v, px);
 }
@@ -986,6 +1050,7 @@ __device__ __forceinline__ void raster_range(const FrameParams &fp, const Edges 
 __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__restrict__ vbo,
                                               const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
                                               const float *__restrict__ tripos, size_t stride,
+                                              const uint4 *__restrict__ triuv, const uint32_t *__restrict__ atlas,
                                               const BinRec *__restrict__ records,
                                               const uint32_t *__restrict__ entries, uint32_t entries_cap,
                                               const BinState *__restrict__ state, uint64_t *__restrict__ vis,
@@ -1103,7 +1168,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
         const BinRec rec = records[uint32_t(keys[c])];  // the key's low word is the winner's record slot
         uint8_t px[4];
         float zw = __uint_as_float(uint32_t(keys[c] >> 32));  // the depth the raster pass computed from this record
-        shade_from_record(fp, vbo, idx, triattr, tripos, stride, rec, i, fp.rows - 1 - rr, px, zw);
+        shade_from_record(fp, vbo, idx, triattr, tripos, stride, triuv, atlas, rec, i, fp.rows - 1 - rr, px, zw);
         if (fp.want_ids) ids[size_t(rr) * fp.cols + i] = rec.id;
         keys[c] = (uint64_t(__float_as_uint(zw)) << 32) |
                   (uint32_t(px[0]) | (uint32_t(px[1]) << 8) | (uint32_t(px[2]) << 16) | (uint32_t(px[3]) << 24));
@@ -1123,7 +1188,10 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
         if (fp.want_ids && bg) ids[cell] = 0xFFFFFFFFu;
         const int ri = ramp_index(int(col & 255u), int((col >> 8) & 255u), int((col >> 16) & 255u), fp.ramp_len);
         if (fp.mode_on) ridx[cell] = uint8_t(ri);
-        else if (rr >= fp.row0 && rr < fp.row1) ascii[cell] = fp.ramp[ri];
+        else if (rr >= fp.row0 && rr < fp.row1) {
+            const uint32_t qa = col >> 24;  // 255 unless an atlas texel put an ASCII override there
+            ascii[cell] = (qa >= 2u && qa <= 254u) ? uint8_t(qa) : fp.ramp[ri];
+        }
     }
 }
 
@@ -1414,7 +1482,10 @@ struct ar_ctx {
     float *d_triattr = nullptr;      // n_tris x 24 floats: the three vertices' normals and colours
     // everything the binning kernels write, per buffer set
     BinRec *d_records[kSets] = {};  // 2 x n_tris setup record slots, filled densely per k_setup workgroup
-    uint8_t *d_flat = nullptr;       // n_tris flags: identical normal and colour at the three vertices
+    uint8_t *d_flat = nullptr;       // n_tris flag bytes: kFlagFlat | kFlagTextured
+    uint4 *d_triuv = nullptr;        // n_tris texel-coordinate rows (ar_set_mesh_uv), else null
+    uint32_t *d_atlas = nullptr;     // atlas texels (ar_set_texture), else null
+    int atlas_w = 0, atlas_h = 0;
     uint2 *d_surv[kSets] = {};  // per k_setup workgroup: cell ranges of its surviving sub-triangles
     uint32_t *d_surv_count[kSets] = {};
     uint32_t *d_dircount[kSets] = {};  // per k_setup workgroup: entries per bin (+ scan scratch)
@@ -1565,6 +1636,10 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
     fp.ya = row0 - halo < 0 ? 0 : row0 - halo;
     fp.yb = row1 + halo > rows ? rows : row1 + halo;
     matmul_pv(ctx->proj, ctx->view, fp.pv);
+    // texturing needs texel coordinates, an atlas, and more than one texel either way (shader_utils.js:94)
+    const bool textured = ctx->d_triuv && ctx->d_atlas && ctx->atlas_w > 1 && ctx->atlas_h > 1;
+    fp.tex_w = textured ? ctx->atlas_w : 0;
+    fp.tex_h = textured ? ctx->atlas_h : 0;
 
     const size_t strip_cells = size_t(fp.yb - fp.ya) * cols;
     const unsigned cell_blocks = unsigned((strip_cells + 255) / 256);
@@ -1674,7 +1749,8 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
         {
             Stamper s(ctx, K_TILE, fs);
             k_tile<<<unsigned((nbins + 7) / 8 * 8) << (2 * fp.bshift), 256, 0, fs>>>(
-                fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_tripos, ctx->tripos_stride, ctx->d_records[set], ctx->d_entries[set],
+                fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_tripos, ctx->tripos_stride, ctx->d_triuv, ctx->d_atlas,
+                ctx->d_records[set], ctx->d_entries[set],
                 ctx->pool_cap, ctx->d_state, ctx->d_vis[set], ctx->d_rgba[oset], ctx->d_depth[oset], ascii_out, ctx->d_ridx[set],
                 ctx->d_ids[oset]);
         }
@@ -1696,13 +1772,16 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
         }
         {
             Stamper s(ctx, K_SHADE);
-            k_shade<<<cell_blocks, 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_vis[0], ctx->d_rgba[0], ctx->d_depth[0],
+            k_shade<<<cell_blocks, 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triuv, ctx->d_atlas, ctx->d_vis[0],
+                                                         ctx->d_rgba[0], ctx->d_depth[0],
                                                          ascii_out, ctx->d_ridx[0], ctx->d_ids[0], ctx->d_counters);
         }
     }
     if (fp.mode_on == 1) {
         Stamper s(ctx, K_ASCII, fs);
-        launch_ascii<false>(fp, ctx->d_ridx[tiled ? set : 0], ascii_out, fs);
+        // a textured frame can hold ASCII overrides in its alpha bytes, which the plane of ramp indices cannot express
+        if (textured) launch_ascii<true>(fp, ctx->d_rgba[oset], ascii_out, fs);
+        else launch_ascii<false>(fp, ctx->d_ridx[tiled ? set : 0], ascii_out, fs);
     }
     AR_HIP(ctx, hipGetLastError());
     ctx->vis_clean = true;
@@ -1765,6 +1844,7 @@ void ar_destroy(ar_ctx *ctx) {
     (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii); (void)hipFree(ctx->d_q_colors);
     (void)hipFree(ctx->d_p_atlas); (void)hipFree(ctx->d_p_cov); (void)hipFree(ctx->d_p_image);
     (void)hipFree(ctx->d_state); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr); (void)hipFree(ctx->d_flat);
+    (void)hipFree(ctx->d_triuv); (void)hipFree(ctx->d_atlas);
     for (int k = 0; k < kSets; k++) {
         (void)hipFree(ctx->d_entries[k]); (void)hipFree(ctx->d_surv[k]); (void)hipFree(ctx->d_surv_count[k]);
         (void)hipFree(ctx->d_dircount[k]); (void)hipFree(ctx->d_records[k]);
@@ -1788,10 +1868,10 @@ int ar_set_mesh(ar_ctx *ctx, const float *vbo9, uint32_t n_verts, const uint32_t
     int rc = sync_streams(ctx);
     if (rc) return rc;
     (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr);
-    (void)hipFree(ctx->d_records[0]); (void)hipFree(ctx->d_records[1]); (void)hipFree(ctx->d_flat);
+    (void)hipFree(ctx->d_flat); (void)hipFree(ctx->d_triuv);
+    for (int k = 0; k < kSets; k++) { (void)hipFree(ctx->d_records[k]); ctx->d_records[k] = nullptr; }
     ctx->d_vbo = nullptr; ctx->d_idx = nullptr; ctx->d_tripos = nullptr; ctx->d_triattr = nullptr;
-    ctx->d_records[0] = ctx->d_records[1] = nullptr;
-    ctx->d_flat = nullptr;
+    ctx->d_flat = nullptr; ctx->d_triuv = nullptr;  // texel coordinates belong to the mesh they were given for
     ctx->n_verts = 0; ctx->n_tris = 0;
     if (!n_tris) return 0;
     AR_HIP(ctx, hipMalloc(&ctx->d_vbo, size_t(n_verts) * 9 * sizeof(float)));
@@ -1809,6 +1889,43 @@ int ar_set_mesh(ar_ctx *ctx, const float *vbo9, uint32_t n_verts, const uint32_t
     AR_HIP(ctx, hipGetLastError());
     AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_verts = n_verts; ctx->n_tris = n_tris;
+    return 0;
+}
+
+int ar_set_mesh_uv(ar_ctx *ctx, const uint16_t *uv8, uint32_t n_tris) {
+    if (!ctx) return AR_E_ARG;
+    if (uv8 && n_tris != ctx->n_tris)
+        return fail(ctx, AR_E_ARG, "ar_set_mesh_uv: %u rows for a mesh of %u triangles", n_tris, ctx->n_tris);
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = sync_streams(ctx);
+    if (rc) return rc;
+    (void)hipFree(ctx->d_triuv);
+    ctx->d_triuv = nullptr;
+    if (!ctx->n_tris) return 0;
+    if (uv8) {
+        AR_HIP(ctx, hipMalloc(&ctx->d_triuv, size_t(n_tris) * sizeof(uint4)));
+        AR_HIP(ctx, hipMemcpy(ctx->d_triuv, uv8, size_t(n_tris) * sizeof(uint4), hipMemcpyHostToDevice));
+    }
+    k_uvflags<<<(ctx->n_tris + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_triuv, ctx->n_tris, ctx->d_flat);
+    AR_HIP(ctx, hipGetLastError());
+    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ar_set_texture(ar_ctx *ctx, const uint8_t *rgba, int width, int height) {
+    if (!ctx) return AR_E_ARG;
+    if (rgba && (width < 1 || height < 1 || width > 16384 || height > 16384))
+        return fail(ctx, AR_E_ARG, "ar_set_texture: bad atlas size %d x %d", width, height);
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = sync_streams(ctx);
+    if (rc) return rc;
+    (void)hipFree(ctx->d_atlas);
+    ctx->d_atlas = nullptr;
+    ctx->atlas_w = ctx->atlas_h = 0;
+    if (!rgba) return 0;
+    AR_HIP(ctx, hipMalloc(&ctx->d_atlas, size_t(width) * height * 4));
+    AR_HIP(ctx, hipMemcpy(ctx->d_atlas, rgba, size_t(width) * height * 4, hipMemcpyHostToDevice));
+    ctx->atlas_w = width; ctx->atlas_h = height;
     return 0;
 }
 

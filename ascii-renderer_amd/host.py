@@ -198,15 +198,60 @@ def _geom_list(scene, key):
     return v if _truthy(v) else []
 
 
-def build_geometry(scene):
+def _u16(v):
+    """Texel coordinate as the path tracer uploads it, (v|0)>>>0 (pathtrace.js:186-195,230-234), kept to
+    the 16 bits SceneBuilder stores (scene_api.js:28-31)."""
+    try:
+        f = float(v)
+    except (TypeError, ValueError):
+        return 0
+    if f != f or f in (float("inf"), float("-inf")):
+        return 0
+    n = int(f)                      # JS |0 truncates toward zero (values here are far below 2^31)
+    return 0 if n < 0 else (0xFFFF if n > 0xFFFF else n)
+
+
+def _uv(prim, key):
+    uv = prim.get(key)
+    if not _truthy(uv):
+        return (0, 0)
+    return (_u16(_idx_or(uv, 0, 0)), _u16(_idx_or(uv, 1, 0)))
+
+
+def resolve_color_table(scene, prim):
+    """Albedo of a SceneBuilder primitive: materials.table[matId].albedo (scene_api.js:196-207) when the
+    scene carries such a table, else raster.js's own rule."""
+    mats = scene.get("materials")
+    table = mats.get("table") if isinstance(mats, dict) else None
+    if isinstance(table, dict) and _is_finite_number(prim.get("matId")):
+        M = table.get(str(int(prim["matId"])))
+        alb = M.get("albedo") if isinstance(M, dict) else None
+        if _truthy(alb):
+            return tuple(_clamp01(_num_or_zero(alb[k] if k < len(alb) else None)) for k in range(3))
+    return resolve_color(scene, prim.get("mat"), prim.get("m"))
+
+
+def build_geometry(scene, textured=False):
     """Scene object -> (vbo float32[V, 9] = pos3|nrm3|col3, idx uint32[T*3]) as raster.js:148-257.
 
     Ingests `tris`, `planes`, `spheres` (top level or under `geometry`); `quads` are ignored exactly
     as the reference ignores them.  Returns empty arrays for a null scene.
+
+    textured=True goes beyond the reference's raster backend (which draws neither quads nor textures)
+    and returns (vbo, idx, uv8): `quads` are appended after everything else, two-sided as in the path
+    tracer (iTriangle flips the normal towards the viewer, shader_utils.js:54-55): halves (a,b,c) and
+    (a,c,d) (shader_utils.js:190-191) plus the same two with reversed winding, of which back-face culling
+    keeps one pair; colours resolve through materials.table when the scene has one; uv8 holds one row
+    (u0, v0, u1, v1, u2, v2, flags, 0) per triangle for ar_set_mesh_uv, flags bit 0 set where the path
+    tracer would sample the atlas: every `tris` item (sampleTriFetch), a quad half unless its three
+    coordinate pairs are all zero (sampleQuadFetch, shader_utils.js:108-132).
     """
     if not scene:
-        return np.zeros((0, 9), dtype=np.float32), np.zeros(0, dtype=np.uint32)
+        empty = (np.zeros((0, 9), dtype=np.float32), np.zeros(0, dtype=np.uint32))
+        return empty + (np.zeros((0, 8), dtype=np.uint16),) if textured else empty
     pos, nrm, col, idx = [], [], [], []
+    uv_rows = {}                     # triangle number -> uv8 row (textured mode)
+    color_of = (lambda prim: resolve_color_table(scene, prim)) if textured else (lambda prim: resolve_color(scene, prim.get("mat"), prim.get("m")))
 
     def push_tri(a, b, c, color):
         U = (b[0] - a[0], b[1] - a[1], b[2] - a[2])
@@ -221,13 +266,14 @@ def build_geometry(scene):
         idx.extend([base, base + 1, base + 2])
 
     for t in _geom_list(scene, "tris"):
-        push_tri(_or(t.get("a"), (0, 0, 0)), _or(t.get("b"), (1, 0, 0)), _or(t.get("c"), (0, 1, 0)),
-                 resolve_color(scene, t.get("mat"), t.get("m")))
+        if textured:
+            uv_rows[len(idx) // 3] = _uv(t, "uvA") + _uv(t, "uvB") + _uv(t, "uvC") + (1, 0)
+        push_tri(_or(t.get("a"), (0, 0, 0)), _or(t.get("b"), (1, 0, 0)), _or(t.get("c"), (0, 1, 0)), color_of(t))
 
     for p in _geom_list(scene, "planes"):
         n = _or(p.get("n"), (0, 1, 0))
         d = p.get("d") if _is_finite_number(p.get("d")) else 0
-        color = resolve_color(scene, p.get("mat"), p.get("m"))
+        color = color_of(p)
         N = _normalize((n[0], n[1], n[2]))
         P0 = (-d * N[0], -d * N[1], -d * N[2])
         tmp = (0, 1, 0) if abs(N[1]) < 0.99 else (1, 0, 0)
@@ -246,7 +292,7 @@ def build_geometry(scene):
     for s in _geom_list(scene, "spheres"):
         c = _or(s.get("p"), (0, 0, 0))
         r = s.get("r") if _is_finite_number(s.get("r")) else 1
-        color = resolve_color(scene, s.get("mat"), s.get("m"))
+        color = color_of(s)
         base_vert = len(pos)
         for iy in range(SPHERE_LAT + 1):
             phi = (iy / SPHERE_LAT) * math.pi
@@ -265,13 +311,32 @@ def build_geometry(scene):
                 i3 = i2 + 1
                 idx.extend([i0, i2, i1, i1, i2, i3])
 
+    if textured:
+        for q in _geom_list(scene, "quads"):
+            a, b, c, d = (_or(q.get("a"), (0, 0, 0)), _or(q.get("b"), (1, 0, 0)), _or(q.get("c"), (1, 1, 0)),
+                          _or(q.get("d"), (0, 1, 0)))                                   # pathtrace.js:215-218
+            u0, u1, u2, u3 = _uv(q, "uv0"), _uv(q, "uv1"), _uv(q, "uv2"), _uv(q, "uv3")
+            color = color_of(q)
+            s1 = 1 if (u0 + u1 + u2) != (0,) * 6 else 0     # half (a,b,c): uv0, uv1, uv2
+            s2 = 1 if (u0 + u2 + u3) != (0,) * 6 else 0     # half (a,c,d): uv0, uv2, uv3
+            for (p0, p1, p2, w0, w1, w2, flag) in ((a, b, c, u0, u1, u2, s1), (a, c, d, u0, u2, u3, s2),
+                                                   (a, c, b, u0, u2, u1, s1), (a, d, c, u0, u3, u2, s2)):
+                uv_rows[len(idx) // 3] = w0 + w1 + w2 + (flag, 0)
+                push_tri(p0, p1, p2, color)
+
     V = len(pos)
     vbo = np.zeros((V, 9), dtype=np.float32)
     if V:
         vbo[:, 0:3] = np.asarray(pos, dtype=np.float64)
         vbo[:, 3:6] = np.asarray(nrm, dtype=np.float64)
         vbo[:, 6:9] = np.asarray(col, dtype=np.float64)
-    return vbo, np.asarray(idx, dtype=np.uint32)
+    idx = np.asarray(idx, dtype=np.uint32)
+    if not textured:
+        return vbo, idx
+    uv8 = np.zeros((idx.size // 3, 8), dtype=np.uint16)
+    for t, row in uv_rows.items():
+        uv8[t] = row
+    return vbo, idx, uv8
 
 
 def mesh_to_vbo(positions, indices, colors=None):

@@ -69,6 +69,8 @@ def random_scene(n_tris=1_000_000, cols=1920, rows=1080, seed=0xA5C11, point_lig
 
 def upload(renderer, sc, ramp=DEFAULT_RAMP, mode_on=True, mode_radius=2, mode_thresh=12):
     renderer.set_mesh(sc["vbo"], sc["idx"])
+    renderer.set_mesh_uv(sc.get("uv8"))        # set_mesh dropped any earlier coordinates; the atlas stays until replaced
+    renderer.set_texture(sc.get("atlas"))
     renderer.set_camera(sc["proj"], sc["view"])
     renderer.set_lights(sc["lights"])
     renderer.set_ascii(ramp, mode_on, mode_radius, mode_thresh)

@@ -45,6 +45,25 @@ const char *ar_last_error(ar_ctx *ctx);
  * Indices >= n_verts make their triangle invisible. */
 int ar_set_mesh(ar_ctx *ctx, const float *vbo9, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris);
 
+/* Integer texel coordinates for atlas texturing, one row of eight u16 per triangle of the current mesh:
+ * (u0, v0, u1, v1, u2, v2, flags, 0) - the uvA/uvB/uvC of scene tris and the uv0..uv3 of quads as
+ * SceneBuilder stores them (js/render/scene_api.js:139-160) and the path tracer uploads them
+ * (js/render/backends/pathtrace.js:186-206,230-246).  flags bit 0: sample the atlas for this triangle
+ * (sampleTriFetch samples every triangle, sampleQuadFetch skips a quad half whose three pairs are all
+ * zero, js/render/backends/shader_utils.js:108-132; the caller encodes the outcome in the bit).
+ * The reference's raster backend draws no textures; this brings its path tracer's primary-ray atlas
+ * rule to the raster path.  uv8 == NULL removes the coordinates; ar_set_mesh removes them too. */
+int ar_set_mesh_uv(ar_ctx *ctx, const uint16_t *uv8, uint32_t n_tris);
+
+/* The RGBA8 atlas exactly as PathTraceBackend._ensureAtlasTexture hands it to texImage2D
+ * (pathtrace.js:341-355): width*height*4 bytes; texel (x, y) is read from row height-1-y
+ * (shader_utils.js:100-102).  Texturing is active while texel coordinates are set and both sizes exceed 1
+ * (shader_utils.js:94).  Per covered cell of a sampling triangle the texel at floor(uv + 0.5) decides
+ * (pathtrace_shader.js:141-152): alpha 32..126 - the cell's RGB is the texel's, unshaded, and its alpha
+ * that code, which the ASCII stage emits verbatim; alpha 1 - the texel's rgb replaces the vertex colour
+ * in the lighting; anything else, or a texel outside the atlas - untextured.  rgba == NULL removes it. */
+int ar_set_texture(ar_ctx *ctx, const uint8_t *rgba, int width, int height);
+
 /* Column-major projection and view matrices, as RasterBackend.render uploads to uProj / uView
  * (raster.js:296-304). */
 int ar_set_camera(ar_ctx *ctx, const float proj[16], const float view[16]);
@@ -68,7 +87,8 @@ int ar_set_strip(ar_ctx *ctx, int row0, int row1);
  * Replaces: RasterBackend.render from the clear to readPixels + flipAndCopy (raster.js:276-361,
  * js/render/gl/context.js:117-124) plus the index half of AsciiPass.draw (js/ascii_pass.js:257-302,
  * js/ascii_pass_shader.js:140-188).  Outputs (each may be NULL; all row 0 = top of the image):
- *   rgba  cols*rows*4 bytes, alpha 255;  depth cols*rows binary32 window depth, 1.0 = background;
+ *   rgba  cols*rows*4 bytes, alpha 255 (an atlas texel's code where ar_set_texture says so);
+ *   depth cols*rows binary32 window depth, 1.0 = background;
  *   ascii cols*rows ASCII codes (== glyph-atlas tile indices, ascii_pass_shader.js:190-199).
  * With no geometry the call succeeds and leaves the output buffers untouched. */
 int ar_render(ar_ctx *ctx, int cols, int rows, uint8_t *rgba, float *depth, uint8_t *ascii);

@@ -20,6 +20,9 @@
  *                                           js/ascii_pass_shader.js:12-16,62-68        ref_quantize.json
  *   alpha override (2..254 = literal code)  ascii_pass_shader.js:153-162               golden vectors
  *   modal (majority) smoothing              ascii_pass_shader.js:77-138,169-185        (GLSL; unpinned)
+ *   integer-UV atlas texturing of           js/render/backends/shader_utils.js:94-132, (GLSL; unpinned; the
+ *   triangles (optional)                    pathtrace_shader.js:125-152,256-258        reference applies it in
+ *                                                                                      its path tracer only)
  *
  * PARITY UNPINNED for the rows marked "WebGL"/"GLSL": that arithmetic runs inside the browser's WebGL
  * implementation, which is not part of the reference tree and has no golden outputs there.  For those
@@ -51,6 +54,13 @@
  *   - fragment shader in binary32 as written in shade(); colour byte = floor(clamp(c,0,1)*255 + 0.5),
  *     alpha 255; clear colour (0,0,0,255).
  *   - output row 0 is the TOP image row (the reference flips after readPixels).
+ *   - texturing (orc_render_textured): u and v are two more varyings (binary32 values of the integer
+ *     texel coordinates), clipped and interpolated like the others; texel = floor(uv + 0.5) per axis,
+ *     ignored when outside the atlas; the atlas is the array as handed to texImage2D, texel (x, y) is
+ *     read from its row height-1-y (shader_utils.js:100-102).  Texel alpha 0: no texture.  Alpha 1: the
+ *     texel's rgb / 255 replaces the vertex colour before shading.  Alpha 32..126: the cell's RGB is
+ *     the texel's RGB bytes, unshaded, and its alpha is the texel's alpha (an ASCII override for the
+ *     quantizer).  Any other alpha: no texture.
  */
 #include <math.h>
 #include <stdint.h>
@@ -59,10 +69,16 @@
 
 #define ORC_MAX_POINT_LIGHTS 8 /* raster_shader.js:5 */
 
+#define ORC_NV 11
 typedef struct {
-    float c[4];   /* clip x,y,z,w */
-    float v[9];   /* varyings: world pos, normal, colour (raster_shader.js:18-20) */
+    float c[4];        /* clip x,y,z,w */
+    float v[ORC_NV];   /* varyings: world pos, normal, colour (raster_shader.js:18-20), then texel u, v */
 } orc_vert;
+
+typedef struct {
+    const uint8_t *rgba;   /* as handed to texImage2D (pathtrace.js:352-353) */
+    int w, h;
+} orc_atlas;
 
 typedef struct {
     float amb[3], ldir[3], lcol[3];
@@ -86,6 +102,7 @@ static void vertex_shader(const float *PV, const float *vtx9, orc_vert *o)
     for (int r = 0; r < 4; r++)
         o->c[r] = ((PV[0 * 4 + r] * x + PV[1 * 4 + r] * y) + PV[2 * 4 + r] * z) + PV[3 * 4 + r];
     for (int k = 0; k < 9; k++) o->v[k] = vtx9[k];
+    o->v[9] = o->v[10] = 0.0f;
 }
 
 /* new vertex on the near plane, always from the inside vertex I towards the outside vertex O */
@@ -93,7 +110,7 @@ static void clip_vertex(const orc_vert *I, float dI, const orc_vert *O, float dO
 {
     const float t = dI / (dI - dO);
     for (int k = 0; k < 4; k++) out->c[k] = I->c[k] + (O->c[k] - I->c[k]) * t;
-    for (int k = 0; k < 9; k++) out->v[k] = I->v[k] + (O->v[k] - I->v[k]) * t;
+    for (int k = 0; k < ORC_NV; k++) out->v[k] = I->v[k] + (O->v[k] - I->v[k]) * t;
 }
 
 /* Near-plane clip of one triangle; returns the number of sub-triangles (0, 1 or 2). */
@@ -161,9 +178,29 @@ static int edge_inside(double E, double a, double b)
     return E > 0.0 || (E == 0.0 && (a > 0.0 || (a == 0.0 && b > 0.0)));
 }
 
-/* Rasterize one (sub-)triangle into the bottom-up work buffers. */
+/*
+ * Atlas lookup for one fragment (shader_utils.js:108-117 with fetchAtlas :100-105; the texel classes of
+ * pathtrace_shader.js:141-152).  Returns 1 when the texel is an ASCII pass-through (out holds the final
+ * RGBA), else 0 with col replaced by the texel colour when the texel is solid.
+ */
+static int apply_texture(const orc_atlas *A, float u, float v, float col[3], uint8_t out[4])
+{
+    const float tx = floorf(u + 0.5f), ty = floorf(v + 0.5f);
+    if (!(tx >= 0.0f) || !(ty >= 0.0f) || !(tx < (float)A->w) || !(ty < (float)A->h)) return 0;
+    const uint8_t *texel = A->rgba + 4 * ((size_t)(A->h - 1 - (int)ty) * A->w + (int)tx);
+    const int a = texel[3];
+    if (a >= 32 && a <= 126) {
+        out[0] = texel[0]; out[1] = texel[1]; out[2] = texel[2]; out[3] = (uint8_t)a;
+        return 1;
+    }
+    if (a == 1)
+        for (int k = 0; k < 3; k++) col[k] = (float)texel[k] / 255.0f;
+    return 0;
+}
+
+/* Rasterize one (sub-)triangle into the bottom-up work buffers.  A: atlas, or NULL for an untextured triangle. */
 static void raster_tri(const orc_vert t[3], uint32_t tri_id, const orc_lights *L, int cols, int rows,
-                       uint8_t *rgba, float *depth, uint32_t *ids)
+                       uint8_t *rgba, float *depth, uint32_t *ids, const orc_atlas *A)
 {
     float X[3], Y[3], W[3], Z[3];
     const float hw = (float)cols * 0.5f, hh = (float)rows * 0.5f;
@@ -218,8 +255,9 @@ static void raster_tri(const orc_vert t[3], uint32_t tri_id, const orc_lights *L
             if (ids) ids[cell] = tri_id;
             const float rS = 1.0f / ((f0 + f1) + f2);
             const float b0 = f0 * rS, b1 = f1 * rS, b2 = f2 * rS;
-            float v[9];
-            for (int q = 0; q < 9; q++) v[q] = (b0 * t[0].v[q] + b1 * t[1].v[q]) + b2 * t[2].v[q];
+            float v[ORC_NV];
+            for (int q = 0; q < ORC_NV; q++) v[q] = (b0 * t[0].v[q] + b1 * t[1].v[q]) + b2 * t[2].v[q];
+            if (A && apply_texture(A, v[9], v[10], v + 6, rgba + cell * 4)) continue;
             shade(v, L, rgba + cell * 4);
         }
     }
@@ -233,12 +271,40 @@ static void raster_tri(const orc_vert t[3], uint32_t tri_id, const orc_lights *L
  * 0xFFFFFFFF = background); any may be NULL.
  * Triangles naming a vertex >= n_verts are skipped.  Returns 0, or -1 on bad arguments.
  */
+int orc_render_textured(const float *vbo9, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris,
+                        const float *proj, const float *view,
+                        const float *amb, const float *ldir, const float *lcol,
+                        int n_pl, const float *plpos, const float *plcol,
+                        int cols, int rows, uint8_t *rgba_out, float *depth_out, uint32_t *ids_out,
+                        const uint16_t *uv8, const uint8_t *atlas_rgba, int atlas_w, int atlas_h);
+
 int orc_render(const float *vbo9, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris,
                const float *proj, const float *view,
                const float *amb, const float *ldir, const float *lcol,
                int n_pl, const float *plpos, const float *plcol,
                int cols, int rows, uint8_t *rgba_out, float *depth_out, uint32_t *ids_out)
 {
+    return orc_render_textured(vbo9, n_verts, idx, n_tris, proj, view, amb, ldir, lcol, n_pl, plpos, plcol, cols, rows,
+                               rgba_out, depth_out, ids_out, NULL, NULL, 0, 0);
+}
+
+/*
+ * orc_render with atlas texturing.  uv8: per triangle eight u16 (u0, v0, u1, v1, u2, v2, flags, 0): integer
+ * texel coordinates of the three vertices (scene_api.js:139-160) and flags bit 0 = "sample the atlas for
+ * this triangle" (the path tracer samples every triangle, and a quad half unless its three coordinate
+ * pairs are all zero, shader_utils.js:108-132; the caller encodes that in the bit).  atlas_rgba: RGBA8
+ * texels as handed to texImage2D; texturing is on when both sizes exceed 1 (shader_utils.js:94).
+ * uv8 == NULL or atlas_rgba == NULL: plain orc_render.
+ */
+int orc_render_textured(const float *vbo9, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris,
+                        const float *proj, const float *view,
+                        const float *amb, const float *ldir, const float *lcol,
+                        int n_pl, const float *plpos, const float *plcol,
+                        int cols, int rows, uint8_t *rgba_out, float *depth_out, uint32_t *ids_out,
+                        const uint16_t *uv8, const uint8_t *atlas_rgba, int atlas_w, int atlas_h)
+{
+    const orc_atlas atlas = { atlas_rgba, atlas_w, atlas_h };
+    const int textured = uv8 && atlas_rgba && atlas_w > 1 && atlas_h > 1;
     if (cols <= 0 || rows <= 0 || n_pl < 0 || n_pl > ORC_MAX_POINT_LIGHTS) return -1;
     const size_t n = (size_t)cols * rows;
     uint8_t *rgba = (uint8_t *)malloc(n * 4);
@@ -265,8 +331,15 @@ int orc_render(const float *vbo9, uint32_t n_verts, const uint32_t *idx, uint32_
         vertex_shader(PV, vbo9 + (size_t)i0 * 9, &in[0]);
         vertex_shader(PV, vbo9 + (size_t)i1 * 9, &in[1]);
         vertex_shader(PV, vbo9 + (size_t)i2 * 9, &in[2]);
+        const int sample = textured && (uv8[8 * (size_t)t + 6] & 1u);
+        if (sample)
+            for (int k = 0; k < 3; k++) {
+                in[k].v[9] = (float)uv8[8 * (size_t)t + 2 * k];
+                in[k].v[10] = (float)uv8[8 * (size_t)t + 2 * k + 1];
+            }
         const int ns = clip_near(in, sub);
-        for (int s = 0; s < ns; s++) raster_tri(sub[s], 2u * t + (uint32_t)s, &L, cols, rows, rgba, depth, ids);
+        for (int s = 0; s < ns; s++)
+            raster_tri(sub[s], 2u * t + (uint32_t)s, &L, cols, rows, rgba, depth, ids, sample ? &atlas : NULL);
     }
     for (int r = 0; r < rows; r++) {                /* flipAndCopy: output row r = GL row rows-1-r */
         const size_t src = (size_t)(rows - 1 - r) * cols, dst = (size_t)r * cols;

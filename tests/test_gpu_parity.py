@@ -26,7 +26,8 @@ def R(pkg, request):
 def _check(pkg, oracle, R, sc, ramp="@%#*+=-:. ", mode=(True, 2, 12), label=""):
     pkg.scenes.upload(R, sc, ramp, *mode)
     out = R.render(sc["cols"], sc["rows"], want_ids=True)
-    rgba, depth, ids = oracle.render(sc["vbo"], sc["idx"], sc["proj"], sc["view"], sc["lights"], sc["cols"], sc["rows"])
+    rgba, depth, ids = oracle.render(sc["vbo"], sc["idx"], sc["proj"], sc["view"], sc["lights"], sc["cols"], sc["rows"],
+                                     uv8=sc.get("uv8"), atlas=sc.get("atlas"))
     ascii_ = oracle.quantize(rgba, sc["cols"], sc["rows"], ramp, int(mode[0]), mode[1], mode[2])
     name = label or sc["name"]
     assert np.array_equal(out["ids"], ids), "%s: %d cells differ in winner" % (name, np.count_nonzero(out["ids"] != ids))
@@ -128,6 +129,99 @@ def test_near_plane_and_huge_triangles(pkg, oracle, R):
                 assert c["medium_records"] > 0 and c["large_records"] > 0
             else:
                 assert c["bin_records"] > 0 and c["pool_overflow"] == 0
+
+
+def _textured_case(golden_dir, pkg, name):
+    with open(os.path.join(golden_dir, "ref_pathtrace_uv.json")) as fh:
+        case = next(c for c in json.load(fh)["cases"] if c["name"] == name)
+    scene = case["scene"]
+    w, h = scene["atlas"]["width"], scene["atlas"]["height"]
+    atlas = np.frombuffer(base64.b64decode(case["atlas_rgba"]), dtype=np.uint8).reshape(h, w, 4)
+    vbo, idx, uv8 = pkg.host.build_geometry(scene, textured=True)
+    return scene, vbo, idx, uv8, atlas
+
+
+def test_textured_reference_scenes(pkg, oracle, R, golden_dir):
+    """Atlas texturing (quads, texel classes, ASCII overrides) on the reference's default scene and on a
+    builder scene with textured triangles: cameras inside the room (every wall crosses the near plane),
+    facing the poster, grazing it; smoothing on and off; the rule itself is pinned in test_texture_cpu.py."""
+    overrides = 0
+    for name, cams in (("default_scene_atlas32", [((0.0, 2.5, 6.0), -math.pi / 2, 0.0, 120, 50), ((0.0, 1.5, 6.0), 0.0, 0.0, 96, 36),
+                                                  ((0.3, 2.6, 3.4), -1.3, 0.1, 333, 77), ((1.4, 4.0, 7.5), -1.9, -0.3, 640, 360)]),
+                       ("builder_textured", [((0.0, 1.0, 4.0), -math.pi / 2, 0.0, 80, 40), ((0.5, 6.0, 0.5), 0.3, -1.4, 257, 130),
+                                             ((-4.5, 1.5, 1.0), 0.4, 0.0, 200, 100)])):
+        scene, vbo, idx, uv8, atlas = _textured_case(golden_dir, pkg, name)
+        lights = pkg.host.pack_lights(scene)
+        lights["ambient"] = (0.3, 0.35, 0.4)
+        lights["pl_pos"], lights["pl_col"] = [(0.0, 3.0, 4.0)], [(4.0, 3.0, 2.0)]
+        for pos, yaw, pitch, cols, rows in cams:
+            proj, view = pkg.host.camera_matrices({"pos": pos, "yaw": yaw, "pitch": pitch}, cols, rows, 0.5)
+            sc = {"name": "%s %dx%d" % (name, cols, rows), "vbo": vbo, "idx": idx, "uv8": uv8, "atlas": atlas, "proj": proj,
+                  "view": view, "lights": lights, "cols": cols, "rows": rows}
+            for mode in ((True, 2, 12), (False, 2, 12)):
+                out, ids = _check(pkg, oracle, R, sc, mode=mode)
+            a = out["rgba"][..., 3]
+            glyph = (a >= 32) & (a <= 126)
+            assert np.all((a == 255) | glyph)
+            assert np.array_equal(out["ascii"][glyph], a[glyph])        # overrides reach the ASCII plane verbatim
+            overrides += int(glyph.sum())
+    assert overrides > 2000
+    # the same renderer goes back to untextured frames
+    sc = pkg.scenes.icosphere_scene(angle=0.3, cols=160, rows=60, subdiv=2)
+    out, _ = _check(pkg, oracle, R, sc)
+    assert np.all(out["rgba"][..., 3] == 255)
+
+
+def test_textured_random_triangles_and_switches(pkg, oracle, R):
+    """Random triangles of every size around and through the camera with random texel coordinates (some
+    beyond the atlas), random sample bits and an atlas of every alpha class; then the switches: an atlas
+    one texel high, no atlas, no coordinates, a strip."""
+    rng = np.random.default_rng(11)
+    T = 4000
+    centre = rng.uniform(-6, 6, size=(T, 1, 3))
+    P = (centre + rng.uniform(-1, 1, size=(T, 3, 3)) * rng.choice([0.1, 0.5, 2.0, 8.0], p=[0.45, 0.45, 0.09, 0.01], size=(T, 1, 1))).reshape(-1, 3)
+    vbo, idx = pkg.host.mesh_to_vbo(P.astype(np.float32), np.arange(T * 3).reshape(-1, 3), rng.uniform(0, 1, size=(T, 3)))
+    W, H = 37, 21
+    uv8 = np.zeros((T, 8), dtype=np.uint16)
+    uv8[:, 0:6:2] = rng.integers(0, W + 6, size=(T, 3))
+    uv8[:, 1:6:2] = rng.integers(0, H + 6, size=(T, 3))
+    uv8[:, 6] = rng.integers(0, 2, size=T)
+    uv8[::97, :6] = 65535
+    atlas = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
+    atlas[..., 3] = rng.choice(np.array([0, 1, 1, 1, 32, 77, 126, 2, 31, 127, 254, 255], dtype=np.uint8), size=(H, W))
+    lights = pkg.host.pack_lights({"lights": {"points": [{"p": [1, 2, 0], "color": [1, 1, 1], "intensity": 4}]}})
+    base = {"name": "textured soup", "vbo": vbo, "idx": idx, "lights": lights}
+    for cols, rows, cam in [(200, 100, {"pos": (0.1, 0.2, 0.3), "yaw": 0.7, "pitch": -0.2}),
+                            (333, 77, {"pos": (3, -2, 1), "yaw": -2.0, "pitch": 0.9})]:
+        proj, view = pkg.host.camera_matrices(cam, cols, rows, 0.5)
+        sc = dict(base, proj=proj, view=view, cols=cols, rows=rows, uv8=uv8, atlas=atlas)
+        out, _ = _check(pkg, oracle, R, sc, mode=(True, 3, 20))
+        assert np.count_nonzero(out["rgba"][..., 3] != 255) > 50
+        _check(pkg, oracle, R, sc, mode=(False, 2, 12))
+        plain, _ = _check(pkg, oracle, R, dict(sc, uv8=None, atlas=None))
+        for variant in (dict(sc, atlas=atlas[:1]), dict(sc, atlas=None), dict(sc, uv8=None)):
+            got, _ = _check(pkg, oracle, R, variant)
+            assert np.array_equal(got["rgba"], plain["rgba"])
+    # a strip of a textured frame equals the same rows of the full frame
+    pkg.scenes.upload(R, sc, "@%#*+=-:. ", True, 2, 12)
+    full = R.render(cols, rows)
+    R.set_strip(20, 50)
+    part = R.render(cols, rows)
+    R.set_strip(0, 0)
+    for k in ("rgba", "depth", "ascii"):
+        assert np.array_equal(part[k][20:50], full[k][20:50]), k
+
+
+def test_texture_argument_errors(pkg, R):
+    sc = pkg.scenes.cube_scene()
+    pkg.scenes.upload(R, sc)
+    with pytest.raises(pkg.AsciiRastError):
+        R.set_mesh_uv(np.zeros((5, 8), dtype=np.uint16))            # the cube has 12 triangles
+    with pytest.raises(pkg.AsciiRastError):
+        R._check(R._L.ar_set_texture(R._h, np.zeros(4, dtype=np.uint8).ctypes.data_as(pkg.binding._u8p), 0, 1))
+    R.set_mesh_uv(np.zeros((12, 8), dtype=np.uint16))
+    R.set_mesh_uv(None)
+    R.set_texture(None)
 
 
 def test_pool_overflow_falls_back_and_stays_exact(pkg, oracle):
