@@ -866,6 +866,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Bi
 // clip_near builds them.  Which is which follows from the signs of d = z_c + w_c of the three mesh
 // vertices; the varyings are then rebuilt and interpolated one component at a time, which keeps this
 // rarely taken path from setting the register budget of the kernel that contains it.
+template <bool TEX>
 __device__ __forceinline__ void shade_clipped_record(const FrameParams &fp, const float *__restrict__ vbo,
                                                      const uint32_t *__restrict__ idx, const uint4 *__restrict__ triuv,
                                                      const uint32_t *__restrict__ atlas, const BinRec &rec, int i, int j,
@@ -919,7 +920,7 @@ __device__ __forceinline__ void shade_clipped_record(const FrameParams &fp, cons
     };
     float v[9];
     for (int q = 0; q < 9; q++) v[q] = varying(vp[0][q], vp[1][q], vp[2][q]);
-    if ((rec.flags & kFlagTextured) && fp.tex_w > 0) {
+    if (TEX && (rec.flags & kFlagTextured)) {
         const uint4 uv = triuv[t];
         const float tu = varying(float(uv.x & 0xFFFFu), float(uv.y & 0xFFFFu), float(uv.z & 0xFFFFu));
         const float tv = varying(float(uv.x >> 16), float(uv.y >> 16), float(uv.z >> 16));
@@ -932,12 +933,13 @@ __device__ __forceinline__ void shade_clipped_record(const FrameParams &fp, cons
 // colour from the triangle's attribute row (one vertex's worth when the triangle is flat) and world
 // positions from the position planes (only when point lights are on); clipped ones are rebuilt by
 // shade_cell.
+template <bool TEX>
 __device__ __forceinline__ void shade_from_record(const FrameParams &fp, const float *__restrict__ vbo,
                                                   const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
                                                   const float *__restrict__ tripos, size_t stride,
                                                   const uint4 *__restrict__ triuv, const uint32_t *__restrict__ atlas,
                                                   const BinRec &rec, int i, int j, uint8_t (&px)[4], float &zw) {
-    if (rec.flags & kFlagClipped) { shade_clipped_record(fp, vbo, idx, triuv, atlas, rec, i, j, px); return; }  // zw: the key's
+    if (rec.flags & kFlagClipped) { shade_clipped_record<TEX>(fp, vbo, idx, triuv, atlas, rec, i, j, px); return; }  // zw: the key's
     const uint32_t t = rec.id >> 1;
     const float4 *row = reinterpret_cast<const float4 *>(triattr) + size_t(t) * 6;
     const int o1 = (rec.flags & kFlagFlat) ? 0 : 2, o2 = (rec.flags & kFlagFlat) ? 0 : 4;
@@ -966,7 +968,7 @@ __device__ __forceinline__ void shade_from_record(const FrameParams &fp, const f
     } else {
         v[0] = v[1] = v[2] = 0.0f;  // only the point-light loop reads the position
     }
-    if ((rec.flags & kFlagTextured) && fp.tex_w > 0) {
+    if (TEX && (rec.flags & kFlagTextured)) {
         const uint4 uv = triuv[t];
         const float tu = (b0 * float(uv.x & 0xFFFFu) + b1 * float(uv.y & 0xFFFFu)) + b2 * float(uv.z & 0xFFFFu);
         const float tv = (b0 * float(uv.x >> 16) + b1 * float(uv.y >> 16)) + b2 * float(uv.z >> 16);
@@ -1047,6 +1049,8 @@ __device__ __forceinline__ void raster_range(const FrameParams &fp, const Edges 
     }
 }
 
+// TEX: the frame samples an atlas (texel coordinates and atlas are only read then).
+template <bool TEX>
 __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__restrict__ vbo,
                                               const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
                                               const float *__restrict__ tripos, size_t stride,
@@ -1168,7 +1172,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
         const BinRec rec = records[uint32_t(keys[c])];  // the key's low word is the winner's record slot
         uint8_t px[4];
         float zw = __uint_as_float(uint32_t(keys[c] >> 32));  // the depth the raster pass computed from this record
-        shade_from_record(fp, vbo, idx, triattr, tripos, stride, triuv, atlas, rec, i, fp.rows - 1 - rr, px, zw);
+        shade_from_record<TEX>(fp, vbo, idx, triattr, tripos, stride, triuv, atlas, rec, i, fp.rows - 1 - rr, px, zw);
         if (fp.want_ids) ids[size_t(rr) * fp.cols + i] = rec.id;
         keys[c] = (uint64_t(__float_as_uint(zw)) << 32) |
                   (uint32_t(px[0]) | (uint32_t(px[1]) << 8) | (uint32_t(px[2]) << 16) | (uint32_t(px[3]) << 24));
@@ -1190,7 +1194,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
         if (fp.mode_on) ridx[cell] = uint8_t(ri);
         else if (rr >= fp.row0 && rr < fp.row1) {
             const uint32_t qa = col >> 24;  // 255 unless an atlas texel put an ASCII override there
-            ascii[cell] = (qa >= 2u && qa <= 254u) ? uint8_t(qa) : fp.ramp[ri];
+            ascii[cell] = (TEX && qa >= 2u && qa <= 254u) ? uint8_t(qa) : fp.ramp[ri];
         }
     }
 }
@@ -1748,11 +1752,12 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
         }
         {
             Stamper s(ctx, K_TILE, fs);
-            k_tile<<<unsigned((nbins + 7) / 8 * 8) << (2 * fp.bshift), 256, 0, fs>>>(
-                fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_tripos, ctx->tripos_stride, ctx->d_triuv, ctx->d_atlas,
-                ctx->d_records[set], ctx->d_entries[set],
-                ctx->pool_cap, ctx->d_state, ctx->d_vis[set], ctx->d_rgba[oset], ctx->d_depth[oset], ascii_out, ctx->d_ridx[set],
-                ctx->d_ids[oset]);
+            const unsigned grid = unsigned((nbins + 7) / 8 * 8) << (2 * fp.bshift);
+            auto kernel = textured ? k_tile<true> : k_tile<false>;
+            kernel<<<grid, 256, 0, fs>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_tripos, ctx->tripos_stride, ctx->d_triuv,
+                                         ctx->d_atlas, ctx->d_records[set], ctx->d_entries[set], ctx->pool_cap, ctx->d_state,
+                                         ctx->d_vis[set], ctx->d_rgba[oset], ctx->d_depth[oset], ascii_out, ctx->d_ridx[set],
+                                         ctx->d_ids[oset]);
         }
         ctx->frame++;
     } else {

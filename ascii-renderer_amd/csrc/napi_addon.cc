@@ -121,6 +121,38 @@ napi_value js_set_mesh(napi_env env, napi_callback_info info) {
     return nullptr;
 }
 
+// setMeshUv(handle, Uint16Array(8 * nTris) | null): texel-coordinate rows for ar_set_mesh_uv
+napi_value js_set_mesh_uv(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    void *uv;
+    size_t n;
+    if (!get_typed(env, argv[1], napi_uint16_array, &uv, &n, true)) return nullptr;
+    if (n % 8) { napi_throw_range_error(env, nullptr, "setMeshUv: 8 values per triangle expected"); return nullptr; }
+    if (ar_set_mesh_uv(ctx, static_cast<const uint16_t *>(uv), uint32_t(n / 8))) return throw_ar(env, ctx, "ar_set_mesh_uv");
+    return nullptr;
+}
+
+// setTexture(handle, Uint8Array(width * height * 4) | null, width, height): the atlas for ar_set_texture
+napi_value js_set_texture(napi_env env, napi_callback_info info) {
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    void *px;
+    size_t n;
+    if (!get_typed(env, argv[1], napi_uint8_array, &px, &n, true)) return nullptr;
+    const int32_t w = get_i32(env, argv[2]), h = get_i32(env, argv[3]);
+    if (px && (w < 1 || h < 1 || n < size_t(w) * size_t(h) * 4)) {
+        napi_throw_range_error(env, nullptr, "setTexture: pixels shorter than width * height * 4");
+        return nullptr;
+    }
+    if (ar_set_texture(ctx, static_cast<const uint8_t *>(px), w, h)) return throw_ar(env, ctx, "ar_set_texture");
+    return nullptr;
+}
+
 napi_value js_set_camera(napi_env env, napi_callback_info info) {
     napi_value argv[3];
     if (!get_args(env, info, 3, argv)) return nullptr;
@@ -323,6 +355,8 @@ napi_value init(napi_env env, napi_value exports) {
         {"create", nullptr, js_create, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"destroy", nullptr, js_destroy, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setMesh", nullptr, js_set_mesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setMeshUv", nullptr, js_set_mesh_uv, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setTexture", nullptr, js_set_texture, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setCamera", nullptr, js_set_camera, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setLights", nullptr, js_set_lights, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setAscii", nullptr, js_set_ascii, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

@@ -115,13 +115,41 @@ export function resolveColor(scene, mat, m) {
   return FALLBACK_COLOR;
 }
 
+// Texel coordinate as the path tracer uploads it, (v|0)>>>0 (pathtrace.js:186-195,230-234), kept to the 16 bits
+// SceneBuilder stores (scene_api.js:28-31).
+function u16(v) { const n = v | 0; return n < 0 ? 0 : (n > 0xFFFF ? 0xFFFF : n); }
+function uvOf(uv) { return uv ? [u16(uv[0] || 0), u16(uv[1] || 0)] : [0, 0]; }
+
+// Albedo of a SceneBuilder primitive: materials.table[matId].albedo (scene_api.js:196-207) when the scene
+// carries such a table, else raster.js's own rule.
+export function resolveColorTable(scene, prim) {
+  const table = scene && scene.materials && !Array.isArray(scene.materials) ? scene.materials.table : null;
+  if (table && Number.isFinite(prim.matId)) {
+    const M = table[String(prim.matId | 0)];
+    if (M && M.albedo) return [clamp01(+M.albedo[0] || 0), clamp01(+M.albedo[1] || 0), clamp01(+M.albedo[2] || 0)];
+  }
+  return resolveColor(scene, prim.mat, prim.m);
+}
+
 // Scene object -> { vbo: Float32Array(9 * V) (pos, normal, colour), idx: Uint32Array(3 * T) }, the
 // buffers RasterBackend._rebuildGeometry uploads (raster.js:148-257): tris (flat normal), planes
 // (two triangles of half-size 20), spheres (12 x 16 UV mesh); quads are ignored as in the reference.
-export function buildGeometry(scene) {
-  if (!scene) return { vbo: new Float32Array(0), idx: new Uint32Array(0) };
+//
+// opts.textured goes beyond the reference's raster backend (which draws neither quads nor textures) and
+// adds `uv8` to the result: quads are appended after everything else, two-sided as in the path tracer
+// (iTriangle turns the normal towards the viewer, shader_utils.js:54-55) - halves (a,b,c) and (a,c,d)
+// (shader_utils.js:190-191) plus the same two with reversed winding, of which back-face culling keeps
+// one pair; colours resolve through materials.table when the scene has one; uv8 holds one row
+// (u0, v0, u1, v1, u2, v2, flags, 0) per triangle for ar_set_mesh_uv, flags bit 0 set where the path
+// tracer would sample the atlas: every `tris` item (sampleTriFetch), a quad half unless its three
+// coordinate pairs are all zero (sampleQuadFetch, shader_utils.js:108-132).
+export function buildGeometry(scene, opts) {
+  const textured = !!(opts && opts.textured);
+  if (!scene) return { vbo: new Float32Array(0), idx: new Uint32Array(0), uv8: textured ? new Uint16Array(0) : undefined };
   if (scene.mesh && scene.mesh.positions && scene.mesh.indices) return meshToVbo(scene.mesh.positions, scene.mesh.indices, scene.mesh.colors);
   const pos = [], nrm = [], col = [], idx = [];
+  const uvRows = [];                 // [triangle number, row] pairs (textured mode)
+  const colorOf = textured ? (p) => resolveColorTable(scene, p) : (p) => resolveColor(scene, p.mat, p.m);
   const pushTri = (a, b, c, color) => {
     const U = [b[0] - a[0], b[1] - a[1], b[2] - a[2]], V = [c[0] - a[0], c[1] - a[1], c[2] - a[2]];
     let N = cross(U, V);
@@ -135,10 +163,11 @@ export function buildGeometry(scene) {
   };
   const G = scene.geometry || {};
   for (const t of (scene.tris || G.tris || [])) {
-    pushTri(t.a || [0, 0, 0], t.b || [1, 0, 0], t.c || [0, 1, 0], resolveColor(scene, t.mat, t.m));
+    if (textured) uvRows.push([idx.length / 3, [...uvOf(t.uvA), ...uvOf(t.uvB), ...uvOf(t.uvC), 1, 0]]);
+    pushTri(t.a || [0, 0, 0], t.b || [1, 0, 0], t.c || [0, 1, 0], colorOf(t));
   }
   for (const p of (scene.planes || G.planes || [])) {
-    const n = p.n || [0, 1, 0], d = Number.isFinite(p.d) ? p.d : 0, color = resolveColor(scene, p.mat, p.m);
+    const n = p.n || [0, 1, 0], d = Number.isFinite(p.d) ? p.d : 0, color = colorOf(p);
     const N = normalize([n[0], n[1], n[2]]);
     const P0 = [-d * N[0], -d * N[1], -d * N[2]];
     const tmp = Math.abs(N[1]) < 0.99 ? [0, 1, 0] : [1, 0, 0];
@@ -148,7 +177,7 @@ export function buildGeometry(scene) {
     pushTri(v0, v1, v2, color); pushTri(v0, v2, v3, color);
   }
   for (const s of (scene.spheres || G.spheres || [])) {
-    const c = s.p || [0, 0, 0], r = Number.isFinite(s.r) ? s.r : 1, color = resolveColor(scene, s.mat, s.m);
+    const c = s.p || [0, 0, 0], r = Number.isFinite(s.r) ? s.r : 1, color = colorOf(s);
     const baseVert = pos.length / 3;
     for (let iy = 0; iy <= SPHERE_LAT; iy++) {
       const phi = (iy / SPHERE_LAT) * Math.PI, sp = Math.sin(phi), cp = Math.cos(phi);
@@ -167,13 +196,28 @@ export function buildGeometry(scene) {
       }
     }
   }
+  if (textured) {
+    for (const q of (scene.quads || G.quads || [])) {
+      const a = q.a || [0, 0, 0], b = q.b || [1, 0, 0], c = q.c || [1, 1, 0], d = q.d || [0, 1, 0];   // pathtrace.js:215-218
+      const u0 = uvOf(q.uv0), u1 = uvOf(q.uv1), u2 = uvOf(q.uv2), u3 = uvOf(q.uv3), color = colorOf(q);
+      const any = (...u) => (u.some((p) => p[0] !== 0 || p[1] !== 0) ? 1 : 0);
+      const s1 = any(u0, u1, u2), s2 = any(u0, u2, u3);
+      for (const [p0, p1, p2, w0, w1, w2, flag] of [[a, b, c, u0, u1, u2, s1], [a, c, d, u0, u2, u3, s2], [a, c, b, u0, u2, u1, s1], [a, d, c, u0, u3, u2, s2]]) {
+        uvRows.push([idx.length / 3, [...w0, ...w1, ...w2, flag, 0]]);
+        pushTri(p0, p1, p2, color);
+      }
+    }
+  }
   const V = pos.length / 3, vbo = new Float32Array(V * 9);
   for (let i = 0; i < V; i++) {
     vbo[i * 9] = pos[i * 3]; vbo[i * 9 + 1] = pos[i * 3 + 1]; vbo[i * 9 + 2] = pos[i * 3 + 2];
     vbo[i * 9 + 3] = nrm[i * 3]; vbo[i * 9 + 4] = nrm[i * 3 + 1]; vbo[i * 9 + 5] = nrm[i * 3 + 2];
     vbo[i * 9 + 6] = col[i * 3]; vbo[i * 9 + 7] = col[i * 3 + 1]; vbo[i * 9 + 8] = col[i * 3 + 2];
   }
-  return { vbo, idx: new Uint32Array(idx) };
+  if (!textured) return { vbo, idx: new Uint32Array(idx) };
+  const uv8 = new Uint16Array((idx.length / 3) * 8);
+  for (const [t, row] of uvRows) uv8.set(row, t * 8);
+  return { vbo, idx: new Uint32Array(idx), uv8 };
 }
 
 // Typed-array fast path: indexed mesh -> the reference's unshared, flat-shaded layout without any
@@ -234,6 +278,10 @@ export class HipRasterBackend {
     this._width = 0; this._height = 0;
     this._lastTopDown = null;   // last frame, row 0 = top
     this._forceDirect = !!(opts && opts.directPath);
+    // Beyond the reference's raster backend: draw the scene's quads (two-sided) and apply scene.atlas through the
+    // texel coordinates of tris and quads, as the path tracer's primary ray does.  Off by default, which keeps
+    // frames identical to the reference's rasterizer; may be set on the instance before setScene.
+    this.renderQuads = !!(opts && opts.renderQuads);
     this._pinned = new WeakSet();  // framebuffers handed out by allocFramebuffer
   }
 
@@ -269,9 +317,17 @@ export class HipRasterBackend {
   setScene(scene) {
     this._scene = scene || null;
     this._ensure();
-    const g = buildGeometry(this._scene);
-    native().setMesh(this._h, g.vbo, g.idx);
+    const g = buildGeometry(this._scene, { textured: this.renderQuads });
+    const N = native();
+    N.setMesh(this._h, g.vbo, g.idx);
     this._hasGeometry = g.idx.length > 0;
+    const A = this.renderQuads && this._scene ? this._scene.atlas : null;   // {width, height, pixels}: pathtrace.js:341-355
+    if (g.uv8 && g.uv8.length && A && A.pixels && A.width && A.height) {
+      N.setMeshUv(this._h, g.uv8);
+      N.setTexture(this._h, A.pixels instanceof Uint8Array ? A.pixels : new Uint8Array(A.pixels), A.width | 0, A.height | 0);
+    } else {
+      N.setTexture(this._h, null, 0, 0);
+    }
   }
 
   render(timeSec, framebuffer, appState) {

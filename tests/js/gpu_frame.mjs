@@ -97,6 +97,31 @@ const dump = (name, ta) => fs.writeFileSync(path.join(outDir, name), Buffer.from
     direct.dispose();
   }
 
+  // beyond the reference's rasterizer: the default scene with its quads and an atlas, camera facing the poster
+  {
+    const hb = await import(path.join(JS, 'hip_backend.js'));
+    const uvRef = JSON.parse(fs.readFileSync(path.join(here, '..', 'golden', 'ref_pathtrace_uv.json'), 'utf8'));
+    const c = uvRef.cases.find((x) => x.name === 'default_scene_atlas32');
+    const scene = c.scene;
+    scene.atlas = { width: 32, height: 32, pixels: new Uint8Array(Buffer.from(c.atlas_rgba, 'base64')) };
+    const tb = new hb.HipRasterBackend({ renderQuads: true });
+    tb.setScene(scene);
+    const tcam = { pos: [0.0, 2.5, 6.0], yaw: -Math.PI / 2, pitch: 0.0 }, cols = 120, rows = 50;
+    setCamera(tcam.pos, tcam.yaw, tcam.pitch);
+    const fb = tb.allocFramebuffer(cols, rows), state = { cols, rows, depth: new Float32Array(cols * rows), ascii: new Uint8Array(cols * rows) };
+    tb.render(0.0, fb, state);
+    const g = hb.buildGeometry(scene, { textured: true });
+    dump('poster.rgba', fb); dump('poster.depth', state.depth); dump('poster.ascii', state.ascii);
+    dump('poster.vbo', g.vbo); dump('poster.idx', g.idx); dump('poster.uv8', g.uv8);
+    meta.textured = { name: 'poster', cols, rows, cam: tcam, pixelAspect: config.PATH_TRACER.PIXEL_ASPECT };
+    // the same backend with the switch off draws what the reference's rasterizer draws: two spheres, no overrides
+    tb.renderQuads = false;
+    tb.setScene(scene);
+    tb.render(0.0, fb, state);
+    dump('poster_plain.rgba', fb);
+    tb.dispose();
+  }
+
   // empty scene: early return, buffers untouched (raster.js:274)
   router.setScene({});
   const untouched = new Uint8ClampedArray(80 * 40 * 4).fill(9);

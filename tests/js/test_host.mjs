@@ -66,6 +66,30 @@ const sha = (ta) => crypto.createHash('sha256').update(Buffer.from(ta.buffer, ta
   const cubeMesh = geometry.cube(0.5);
   ok(sceneApi.createSceneBuilder().addMesh(cubeMesh).toObject().geometry.tris.length === 12, 'addMesh with typed arrays');
 
+  /* ---- quads + texel coordinates (beyond the reference's rasterizer) vs the path tracer's recorded uploads ---- */
+  const uvRef = JSON.parse(fs.readFileSync(path.join(goldenDir, 'ref_pathtrace_uv.json'), 'utf8'));
+  results.textured = {};
+  for (const c of uvRef.cases) {
+    const plain = hb.buildGeometry(c.scene), g = hb.buildGeometry(c.scene, { textured: true });
+    ok(plain.uv8 === undefined && g.uv8.length === (g.idx.length / 3) * 8, 'uv8 shape: ' + c.name);
+    const nT = c.uniforms.uNumTris, nQ = c.uniforms.uNumQuads, first = plain.idx.length / 3;
+    ok(g.idx.length / 3 === first + 4 * nQ && bytesEqual(g.idx.subarray(0, plain.idx.length), plain.idx), 'quads are appended: ' + c.name);
+    for (let t = 0; t < nT; t++) {
+      const want = ['A', 'B', 'C'].flatMap((k) => Array.from(u32(c.uniforms['uTriUV' + k + '[0]']).subarray(2 * t, 2 * t + 2)));
+      assert.deepStrictEqual(Array.from(g.uv8.subarray(8 * t, 8 * t + 8)), [...want, 1, 0]);
+    }
+    results.checks += nT;
+    for (let q = 0; q < nQ; q++) {
+      const u = [0, 1, 2, 3].map((k) => Array.from(u32(c.uniforms['uQuadUV' + k + '[0]']).subarray(2 * q, 2 * q + 2)));
+      const any = (...v) => (v.flat().some((x) => x !== 0) ? 1 : 0);
+      const want = [[...u[0], ...u[1], ...u[2], any(u[0], u[1], u[2]), 0], [...u[0], ...u[2], ...u[3], any(u[0], u[2], u[3]), 0],
+        [...u[0], ...u[2], ...u[1], any(u[0], u[1], u[2]), 0], [...u[0], ...u[3], ...u[2], any(u[0], u[2], u[3]), 0]];
+      for (let k = 0; k < 4; k++) assert.deepStrictEqual(Array.from(g.uv8.subarray(8 * (first + 4 * q + k), 8 * (first + 4 * q + k) + 8)), want[k]);
+    }
+    results.checks += nQ;
+    results.textured[c.name] = { uv8: sha(g.uv8), idx: sha(g.idx), verts: g.vbo.length / 9 };
+  }
+
   /* ---- router semantics (js/gpu_renderer.js:52-111 of the reference) ---- */
   assert.throws(() => router.registerBackend('', () => ({})), /registerBackend\(name, factory\): invalid args/);
   assert.throws(() => router.registerBackend('x', 42), /invalid args/);

@@ -59,3 +59,30 @@ def test_node_harness_frames_match_oracle(pkg, oracle, tmp_path):
     colors = np.fromfile(tmp_path / "ico_ui.colors", dtype=np.uint32).reshape(360, 640)
     assert np.array_equal(colors, oracle.quantize_colors(ui, 640, 360, len(ramp)))
     assert np.unique(colors).size > 10 and not colors[5, 10:21].any()      # the UI text cells are black
+
+    # quads + atlas through the JS backend (renderQuads): geometry and texel rows as the JS host built them
+    import base64
+    tx = meta["textured"]
+    cols, rows = tx["cols"], tx["rows"]
+    with open(os.path.join(ROOT, "tests", "golden", "ref_pathtrace_uv.json")) as fh:
+        case = next(c for c in json.load(fh)["cases"] if c["name"] == "default_scene_atlas32")
+    atlas = np.frombuffer(base64.b64decode(case["atlas_rgba"]), dtype=np.uint8).reshape(32, 32, 4)
+    vbo = np.fromfile(tmp_path / "poster.vbo", dtype=np.float32).reshape(-1, 9)
+    idx = np.fromfile(tmp_path / "poster.idx", dtype=np.uint32)
+    uv8 = np.fromfile(tmp_path / "poster.uv8", dtype=np.uint16).reshape(-1, 8)
+    py_vbo, py_idx, py_uv8 = pkg.host.build_geometry(case["scene"], textured=True)
+    assert np.array_equal(idx, py_idx) and np.array_equal(uv8, py_uv8) and np.allclose(vbo, py_vbo, atol=1e-6)
+    proj, view = pkg.host.camera_matrices(tx["cam"], cols, rows, tx["pixelAspect"])
+    lights = pkg.host.pack_lights(case["scene"])
+    rgba, depth, _ = oracle.render(vbo, idx, proj, view, lights, cols, rows, uv8=uv8, atlas=atlas)
+    got = np.fromfile(tmp_path / "poster.rgba", dtype=np.uint8).reshape(rows, cols, 4)
+    assert np.array_equal(got, rgba)
+    assert np.array_equal(np.fromfile(tmp_path / "poster.depth", dtype=np.float32).view(np.uint32), depth.view(np.uint32).reshape(-1))
+    assert np.array_equal(np.fromfile(tmp_path / "poster.ascii", dtype=np.uint8).reshape(rows, cols), oracle.quantize(rgba, cols, rows, ramp, 1, 2, 12))
+    glyph = (rgba[..., 3] >= 32) & (rgba[..., 3] <= 126)
+    assert glyph.sum() > 100
+    ref_vbo, ref_idx = pkg.host.build_geometry(case["scene"])
+    plain = oracle.render(ref_vbo, ref_idx, proj, view, lights, cols, rows)[0]
+    got_plain = np.fromfile(tmp_path / "poster_plain.rgba", dtype=np.uint8).reshape(rows, cols, 4)
+    # (sphere vertices come from libm sin/cos, which V8 and glibc may round differently in the last place)
+    assert np.mean(got_plain == plain) > 0.999 and np.all(got_plain[..., 3] == 255)

@@ -44,3 +44,12 @@ def test_js_and_python_generators_are_bit_identical(js_results, pkg):
     assert h["rm_pos"] == _sha(P) and h["rm_col"] == _sha(C)
     assert h["rm_vbo"] == _sha(pkg.host.mesh_to_vbo(P, I, C)[0])
     assert js_results["mulberry"] == list(pkg.geometry.mulberry32_stream(12345, 3))
+
+
+def test_js_and_python_texel_coordinate_rows_are_identical(js_results, pkg, golden_dir):
+    with open(os.path.join(golden_dir, "ref_pathtrace_uv.json")) as fh:
+        cases = json.load(fh)["cases"]
+    for c in cases:
+        vbo, idx, uv8 = pkg.host.build_geometry(c["scene"], textured=True)
+        got = js_results["textured"][c["name"]]
+        assert got["uv8"] == _sha(uv8) and got["idx"] == _sha(idx) and got["verts"] == vbo.shape[0], c["name"]
