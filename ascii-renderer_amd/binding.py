@@ -15,7 +15,7 @@ EXPORTS = [
     "ar_set_ascii", "ar_set_strip", "ar_set_id_output", "ar_render", "ar_render_async", "ar_sync", "ar_read",
     "ar_device_buffer", "ar_stream", "ar_host_alloc", "ar_host_free", "ar_stream_wait_frame", "ar_frame_wait_stream", "ar_set_stream",
     "ar_set_ascii_target", "ar_quantize", "ar_quantize_colors", "ar_read_colors", "ar_present", "ar_set_profiling", "ar_kernel_stats",
-    "ar_frame_counters", "ar_set_option", "ar_set_mesh_uv", "ar_set_texture",
+    "ar_frame_counters", "ar_set_option", "ar_set_mesh_uv", "ar_set_texture", "ar_set_mesh_indexed", "ar_read_mesh",
 ]
 _lib = None
 
@@ -46,6 +46,8 @@ def load_library():
     L.ar_last_error.argtypes = [vp]
     L.ar_last_error.restype = ctypes.c_char_p
     L.ar_set_mesh.argtypes = [vp, _fp, ctypes.c_uint32, _u32p, ctypes.c_uint32]
+    L.ar_set_mesh_indexed.argtypes = [vp, _fp, ctypes.c_uint32, _u32p, ctypes.c_uint32, _fp]
+    L.ar_read_mesh.argtypes = [vp, _fp, _u32p, _u32p, _u32p]
     L.ar_set_mesh_uv.argtypes = [vp, ctypes.POINTER(ctypes.c_uint16), ctypes.c_uint32]
     L.ar_set_texture.argtypes = [vp, _u8p, ctypes.c_int, ctypes.c_int]
     L.ar_set_camera.argtypes = [vp, _fp, _fp]
@@ -80,7 +82,7 @@ def load_library():
     L.ar_set_option.argtypes = [vp, ctypes.c_int, ctypes.c_longlong]
     for name in ("ar_set_id_output", "ar_set_mesh", "ar_set_camera", "ar_set_lights", "ar_set_ascii", "ar_set_strip", "ar_set_id_output", "ar_render",
                  "ar_render_async", "ar_sync", "ar_read", "ar_quantize", "ar_stream_wait_frame", "ar_frame_wait_stream", "ar_set_stream", "ar_set_ascii_target", "ar_quantize_colors", "ar_read_colors", "ar_present", "ar_set_profiling", "ar_kernel_stats",
-                 "ar_frame_counters", "ar_set_option", "ar_set_mesh_uv", "ar_set_texture"):
+                 "ar_frame_counters", "ar_set_option", "ar_set_mesh_uv", "ar_set_texture", "ar_set_mesh_indexed", "ar_read_mesh"):
         getattr(L, name).restype = ctypes.c_int
     _lib = L
     return L
@@ -122,6 +124,30 @@ class Renderer:
         if vbo.size % 9 or idx.size % 3:
             raise ValueError("vbo must hold 9 floats per vertex and idx 3 indices per triangle")
         self._check(self._L.ar_set_mesh(self._h, vp, vbo.size // 9, idx.ctypes.data_as(_u32p), idx.size // 3))
+
+    def set_mesh_indexed(self, positions, indices, colors=None):
+        """Indexed triangle list (positions [V, 3] f32, indices [T, 3] u32, optional per-triangle albedo [T, 3]);
+        the unshared flat-shaded vertex buffer is built on the GPU."""
+        pos, pp = _f32(np.asarray(positions).reshape(-1))
+        ind = np.ascontiguousarray(np.asarray(indices).reshape(-1), dtype=np.uint32)
+        if pos.size % 3 or ind.size % 3:
+            raise ValueError("positions need 3 floats per vertex and indices 3 per triangle")
+        cp = None
+        if colors is not None:
+            col, cp = _f32(np.asarray(colors).reshape(-1))
+            if col.size != ind.size:
+                raise ValueError("colors must hold 3 floats per triangle")
+        self._check(self._L.ar_set_mesh_indexed(self._h, pp, pos.size // 3, ind.ctypes.data_as(_u32p), ind.size // 3, cp))
+
+    def read_mesh(self):
+        """(vbo float32 [V, 9], idx uint32 [3 T]) of the current mesh as held on the GPU."""
+        nv, nt = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        self._check(self._L.ar_read_mesh(self._h, None, None, ctypes.byref(nv), ctypes.byref(nt)))
+        vbo = np.zeros((nv.value, 9), dtype=np.float32)
+        idx = np.zeros(3 * nt.value, dtype=np.uint32)
+        if nt.value:
+            self._check(self._L.ar_read_mesh(self._h, vbo.ctypes.data_as(_fp), idx.ctypes.data_as(_u32p), None, None))
+        return vbo, idx
 
     def set_mesh_uv(self, uv8):
         """uv8: uint16 [n_tris, 8] rows (u0, v0, u1, v1, u2, v2, flags, 0) for the current mesh, or None to remove."""

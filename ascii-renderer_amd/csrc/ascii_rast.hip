@@ -608,6 +608,42 @@ __global__ __launch_bounds__(256) void k_tristream(const float *__restrict__ vbo
     flat[t] = is_flat ? uint8_t(kFlagFlat) : uint8_t(0);
 }
 
+// Indexed mesh -> the reference's unshared, flat-shaded vertex buffer (what _rebuildGeometry's pushTri emits
+// per triangle, raster.js:158-169,222-236): one lane per triangle gathers its three positions, takes the
+// normal normalize(cross(b - a, c - a)) in binary64 - every product and sum rounded on its own, as the
+// JavaScript expression is - with (0, 1, 0) when its length is <= 1e-8, and writes three vertices of
+// (position, normal, colour) plus the indices 3t, 3t+1, 3t+2.  A vertex index beyond the position array
+// yields NaN positions (what a typed array yields there), which every later stage rejects.
+__global__ __launch_bounds__(256) void k_build_vbo(const float *__restrict__ positions, uint32_t n_verts,
+                                                   const uint32_t *__restrict__ indices, uint32_t n_tris,
+                                                   const float *__restrict__ tri_colors, float *__restrict__ vbo,
+                                                   uint32_t *__restrict__ idx) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_tris) return;
+    float p[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t vi = indices[3 * size_t(t) + k];
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) p[k][ax] = vi < n_verts ? positions[3 * size_t(vi) + ax] : __builtin_nanf("");
+    }
+    const double ux = double(p[1][0]) - double(p[0][0]), uy = double(p[1][1]) - double(p[0][1]), uz = double(p[1][2]) - double(p[0][2]);
+    const double vx = double(p[2][0]) - double(p[0][0]), vy = double(p[2][1]) - double(p[0][1]), vz = double(p[2][2]) - double(p[0][2]);
+    double nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+    const double L = sqrt((nx * nx + ny * ny) + nz * nz);
+    if (L > 1e-8) { nx /= L; ny /= L; nz /= L; } else { nx = 0.0; ny = 1.0; nz = 0.0; }
+    const float r = tri_colors ? tri_colors[3 * size_t(t)] : 0.8f, g = tri_colors ? tri_colors[3 * size_t(t) + 1] : 0.8f,
+                b = tri_colors ? tri_colors[3 * size_t(t) + 2] : 0.8f;  // raster.js:145: default albedo
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float *o = vbo + (3 * size_t(t) + k) * 9;
+        o[0] = p[k][0]; o[1] = p[k][1]; o[2] = p[k][2];
+        o[3] = float(nx); o[4] = float(ny); o[5] = float(nz);
+        o[6] = r; o[7] = g; o[8] = b;
+        idx[3 * size_t(t) + k] = 3u * t + uint32_t(k);
+    }
+}
+
 // Copies the "sample the atlas" bit of every triangle's texel-coordinate row into its flag byte (all bits
 // cleared when triuv is null).
 __global__ __launch_bounds__(256) void k_uvflags(const uint4 *__restrict__ triuv, uint32_t n_tris, uint8_t *__restrict__ flat) {
@@ -1612,6 +1648,35 @@ int ensure_targets(ar_ctx *ctx, int cols, int rows) {
     return 0;
 }
 
+// Waits for the frames in flight and releases the current mesh with everything derived from it.
+int drop_mesh(ar_ctx *ctx) {
+    int rc = sync_streams(ctx);
+    if (rc) return rc;
+    (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr);
+    (void)hipFree(ctx->d_flat); (void)hipFree(ctx->d_triuv);
+    for (int k = 0; k < kSets; k++) { (void)hipFree(ctx->d_records[k]); ctx->d_records[k] = nullptr; }
+    ctx->d_vbo = nullptr; ctx->d_idx = nullptr; ctx->d_tripos = nullptr; ctx->d_triattr = nullptr;
+    ctx->d_flat = nullptr; ctx->d_triuv = nullptr;  // texel coordinates belong to the mesh they were given for
+    ctx->n_verts = 0; ctx->n_tris = 0;
+    return 0;
+}
+
+// d_vbo / d_idx hold the new mesh: derive the streams of the tiled path (positions, attribute rows, flag
+// bytes) and allocate its record slots.
+int finish_mesh(ar_ctx *ctx, uint32_t n_verts, uint32_t n_tris) {
+    ctx->tripos_stride = (size_t(n_tris) + 63) / 64 * 64;
+    AR_HIP(ctx, hipMalloc(&ctx->d_tripos, 9 * ctx->tripos_stride * sizeof(float)));
+    AR_HIP(ctx, hipMalloc(&ctx->d_triattr, size_t(n_tris) * 24 * sizeof(float)));
+    for (int k = 0; k < kSets; k++) AR_HIP(ctx, hipMalloc(&ctx->d_records[k], 2 * size_t(n_tris) * sizeof(BinRec)));
+    AR_HIP(ctx, hipMalloc(&ctx->d_flat, size_t(n_tris)));
+    k_tristream<<<(n_tris + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_vbo, ctx->d_idx, n_verts, n_tris, ctx->tripos_stride, ctx->d_tripos,
+                                                              ctx->d_triattr, ctx->d_flat);
+    AR_HIP(ctx, hipGetLastError());
+    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_verts = n_verts; ctx->n_tris = n_tris;
+    return 0;
+}
+
 // Frames whose caller does not wait for them right away (may_overlap) run entirely on one of kSets frame
 // streams, frame f on stream f % kSets, and every buffer a frame writes exists kSets times: consecutive
 // frames share the GPU without a single cross-stream event (each of which costs the host about as much as
@@ -1870,30 +1935,54 @@ int ar_set_mesh(ar_ctx *ctx, const float *vbo9, uint32_t n_verts, const uint32_t
     if (n_tris > 0x7FFFFFFFu) return fail(ctx, AR_E_ARG, "ar_set_mesh: too many triangles (%u)", n_tris);
     if (n_tris && (!vbo9 || !idx || !n_verts)) return fail(ctx, AR_E_ARG, "ar_set_mesh: null buffer with %u triangles", n_tris);
     AR_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = sync_streams(ctx);
-    if (rc) return rc;
-    (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr);
-    (void)hipFree(ctx->d_flat); (void)hipFree(ctx->d_triuv);
-    for (int k = 0; k < kSets; k++) { (void)hipFree(ctx->d_records[k]); ctx->d_records[k] = nullptr; }
-    ctx->d_vbo = nullptr; ctx->d_idx = nullptr; ctx->d_tripos = nullptr; ctx->d_triattr = nullptr;
-    ctx->d_flat = nullptr; ctx->d_triuv = nullptr;  // texel coordinates belong to the mesh they were given for
-    ctx->n_verts = 0; ctx->n_tris = 0;
-    if (!n_tris) return 0;
+    int rc = drop_mesh(ctx);
+    if (rc || !n_tris) return rc;
     AR_HIP(ctx, hipMalloc(&ctx->d_vbo, size_t(n_verts) * 9 * sizeof(float)));
     AR_HIP(ctx, hipMalloc(&ctx->d_idx, size_t(n_tris) * 3 * sizeof(uint32_t)));
     AR_HIP(ctx, hipMemcpy(ctx->d_vbo, vbo9, size_t(n_verts) * 9 * sizeof(float), hipMemcpyHostToDevice));
     AR_HIP(ctx, hipMemcpy(ctx->d_idx, idx, size_t(n_tris) * 3 * sizeof(uint32_t), hipMemcpyHostToDevice));
-    // derived streams of the tiled path (positions, attribute rows, flat flags) and its record slots
-    ctx->tripos_stride = (size_t(n_tris) + 63) / 64 * 64;
-    AR_HIP(ctx, hipMalloc(&ctx->d_tripos, 9 * ctx->tripos_stride * sizeof(float)));
-    AR_HIP(ctx, hipMalloc(&ctx->d_triattr, size_t(n_tris) * 24 * sizeof(float)));
-    for (int k = 0; k < kSets; k++) AR_HIP(ctx, hipMalloc(&ctx->d_records[k], 2 * size_t(n_tris) * sizeof(BinRec)));
-    AR_HIP(ctx, hipMalloc(&ctx->d_flat, size_t(n_tris)));
-    k_tristream<<<(n_tris + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_vbo, ctx->d_idx, n_verts, n_tris, ctx->tripos_stride, ctx->d_tripos,
-                                                              ctx->d_triattr, ctx->d_flat);
-    AR_HIP(ctx, hipGetLastError());
-    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->n_verts = n_verts; ctx->n_tris = n_tris;
+    return finish_mesh(ctx, n_verts, n_tris);
+}
+
+int ar_set_mesh_indexed(ar_ctx *ctx, const float *positions, uint32_t n_verts, const uint32_t *indices, uint32_t n_tris,
+                        const float *tri_colors) {
+    if (!ctx) return AR_E_ARG;
+    if (n_tris > 0x7FFFFFFFu / 3u) return fail(ctx, AR_E_ARG, "ar_set_mesh_indexed: too many triangles (%u)", n_tris);
+    if (n_tris && (!positions || !indices || !n_verts))
+        return fail(ctx, AR_E_ARG, "ar_set_mesh_indexed: null buffer with %u triangles", n_tris);
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = drop_mesh(ctx);
+    if (rc || !n_tris) return rc;
+    float *d_pos = nullptr, *d_col = nullptr;
+    uint32_t *d_ind = nullptr;
+    auto staged = [&]() -> int {
+        AR_HIP(ctx, hipMalloc(&d_pos, size_t(n_verts) * 3 * sizeof(float)));
+        AR_HIP(ctx, hipMalloc(&d_ind, size_t(n_tris) * 3 * sizeof(uint32_t)));
+        if (tri_colors) AR_HIP(ctx, hipMalloc(&d_col, size_t(n_tris) * 3 * sizeof(float)));
+        AR_HIP(ctx, hipMalloc(&ctx->d_vbo, size_t(n_tris) * 27 * sizeof(float)));
+        AR_HIP(ctx, hipMalloc(&ctx->d_idx, size_t(n_tris) * 3 * sizeof(uint32_t)));
+        AR_HIP(ctx, hipMemcpy(d_pos, positions, size_t(n_verts) * 3 * sizeof(float), hipMemcpyHostToDevice));
+        AR_HIP(ctx, hipMemcpy(d_ind, indices, size_t(n_tris) * 3 * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (tri_colors) AR_HIP(ctx, hipMemcpy(d_col, tri_colors, size_t(n_tris) * 3 * sizeof(float), hipMemcpyHostToDevice));
+        k_build_vbo<<<(n_tris + 255) / 256, 256, 0, ctx->stream>>>(d_pos, n_verts, d_ind, n_tris, d_col, ctx->d_vbo, ctx->d_idx);
+        AR_HIP(ctx, hipGetLastError());
+        AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return 0;
+    };
+    rc = staged();
+    (void)hipFree(d_pos); (void)hipFree(d_ind); (void)hipFree(d_col);
+    if (rc) return rc;
+    return finish_mesh(ctx, 3u * n_tris, n_tris);
+}
+
+int ar_read_mesh(ar_ctx *ctx, float *vbo9, uint32_t *idx, uint32_t *n_verts, uint32_t *n_tris) {
+    if (!ctx) return AR_E_ARG;
+    if (n_verts) *n_verts = ctx->n_verts;
+    if (n_tris) *n_tris = ctx->n_tris;
+    if (!ctx->n_tris || (!vbo9 && !idx)) return 0;
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    if (vbo9) AR_HIP(ctx, hipMemcpy(vbo9, ctx->d_vbo, size_t(ctx->n_verts) * 9 * sizeof(float), hipMemcpyDeviceToHost));
+    if (idx) AR_HIP(ctx, hipMemcpy(idx, ctx->d_idx, size_t(ctx->n_tris) * 3 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return 0;
 }
 

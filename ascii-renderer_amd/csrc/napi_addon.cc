@@ -121,6 +121,50 @@ napi_value js_set_mesh(napi_env env, napi_callback_info info) {
     return nullptr;
 }
 
+// setMeshIndexed(handle, Float32Array positions (3 per vertex), Uint32Array indices (3 per triangle),
+//                Float32Array per-triangle albedo (3 per triangle) | null): ar_set_mesh_indexed
+napi_value js_set_mesh_indexed(napi_env env, napi_callback_info info) {
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    void *pos, *ind, *col;
+    size_t np, ni, nc;
+    if (!get_typed(env, argv[1], napi_float32_array, &pos, &np, true)) return nullptr;
+    if (!get_typed(env, argv[2], napi_uint32_array, &ind, &ni, true)) return nullptr;
+    if (!get_typed(env, argv[3], napi_float32_array, &col, &nc, true)) return nullptr;
+    if (np % 3 || ni % 3 || (col && nc != ni)) {
+        napi_throw_range_error(env, nullptr, "setMeshIndexed: 3 floats per vertex, 3 indices and (optionally) 3 colour floats per triangle");
+        return nullptr;
+    }
+    if (ar_set_mesh_indexed(ctx, static_cast<const float *>(pos), uint32_t(np / 3), static_cast<const uint32_t *>(ind), uint32_t(ni / 3),
+                            static_cast<const float *>(col)))
+        return throw_ar(env, ctx, "ar_set_mesh_indexed");
+    return nullptr;
+}
+
+// readMesh(handle) -> {vbo: Float32Array(9 * V), idx: Uint32Array(3 * T)}: ar_read_mesh
+napi_value js_read_mesh(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    uint32_t nv = 0, nt = 0;
+    if (ar_read_mesh(ctx, nullptr, nullptr, &nv, &nt)) return throw_ar(env, ctx, "ar_read_mesh");
+    void *vdata = nullptr, *idata = nullptr;
+    napi_value vbuf, ibuf, vbo, idx, out;
+    NAPI_OK(env, napi_create_arraybuffer(env, size_t(nv) * 9 * sizeof(float), &vdata, &vbuf));
+    NAPI_OK(env, napi_create_arraybuffer(env, size_t(nt) * 3 * sizeof(uint32_t), &idata, &ibuf));
+    if (nt && ar_read_mesh(ctx, static_cast<float *>(vdata), static_cast<uint32_t *>(idata), nullptr, nullptr))
+        return throw_ar(env, ctx, "ar_read_mesh");
+    NAPI_OK(env, napi_create_typedarray(env, napi_float32_array, size_t(nv) * 9, vbuf, 0, &vbo));
+    NAPI_OK(env, napi_create_typedarray(env, napi_uint32_array, size_t(nt) * 3, ibuf, 0, &idx));
+    NAPI_OK(env, napi_create_object(env, &out));
+    NAPI_OK(env, napi_set_named_property(env, out, "vbo", vbo));
+    NAPI_OK(env, napi_set_named_property(env, out, "idx", idx));
+    return out;
+}
+
 // setMeshUv(handle, Uint16Array(8 * nTris) | null): texel-coordinate rows for ar_set_mesh_uv
 napi_value js_set_mesh_uv(napi_env env, napi_callback_info info) {
     napi_value argv[2];
@@ -355,6 +399,8 @@ napi_value init(napi_env env, napi_value exports) {
         {"create", nullptr, js_create, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"destroy", nullptr, js_destroy, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setMesh", nullptr, js_set_mesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setMeshIndexed", nullptr, js_set_mesh_indexed, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"readMesh", nullptr, js_read_mesh, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setMeshUv", nullptr, js_set_mesh_uv, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setTexture", nullptr, js_set_texture, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setCamera", nullptr, js_set_camera, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

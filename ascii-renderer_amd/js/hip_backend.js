@@ -317,8 +317,16 @@ export class HipRasterBackend {
   setScene(scene) {
     this._scene = scene || null;
     this._ensure();
-    const g = buildGeometry(this._scene, { textured: this.renderQuads });
     const N = native();
+    const M = this._scene && this._scene.mesh;
+    if (M && M.positions instanceof Float32Array && M.indices instanceof Uint32Array && (!M.colors || M.colors instanceof Float32Array)) {
+      // typed-array scene: the unshared flat-shaded vertex buffer (what meshToVbo returns) is built on the GPU
+      N.setMeshIndexed(this._h, M.positions, M.indices, M.colors || null);
+      N.setTexture(this._h, null, 0, 0);
+      this._hasGeometry = M.indices.length >= 3;
+      return;
+    }
+    const g = buildGeometry(this._scene, { textured: this.renderQuads });
     N.setMesh(this._h, g.vbo, g.idx);
     this._hasGeometry = g.idx.length > 0;
     const A = this.renderQuads && this._scene ? this._scene.atlas : null;   // {width, height, pixels}: pathtrace.js:341-355
@@ -379,6 +387,9 @@ export class HipRasterBackend {
     }
     return bottomUp();                                   // raw image as read back: bottom-up
   }
+
+  // The vertex and index buffers as the GPU holds them (what the reference hands to gl.bufferData).
+  readMesh() { this._ensure(); return native().readMesh(this._h); }
 
   frameCounters() {
     this._ensure();

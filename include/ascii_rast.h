@@ -45,6 +45,21 @@ const char *ar_last_error(ar_ctx *ctx);
  * Indices >= n_verts make their triangle invisible. */
 int ar_set_mesh(ar_ctx *ctx, const float *vbo9, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris);
 
+/* ar_set_mesh for an indexed triangle list, with the vertex buffer built on the GPU: positions = n_verts x 3
+ * binary32, indices = n_tris x 3 u32, tri_colors = n_tris x 3 binary32 albedo or NULL for (0.8, 0.8, 0.8).
+ * Produces exactly the buffers RasterBackend._rebuildGeometry builds by pushing every triangle through
+ * pushTri (raster.js:158-169,222-236): three unshared vertices per triangle carrying the flat normal
+ * normalize(cross(b-a, c-a)) evaluated in binary64 ((0,1,0) when its length is <= 1e-8) and the albedo,
+ * indices 0..3*n_tris-1.  Replaces that O(triangles) JavaScript loop and shrinks the upload from 120 to
+ * 24-36 bytes per triangle.  An index >= n_verts gives its triangle NaN positions (invisible). */
+int ar_set_mesh_indexed(ar_ctx *ctx, const float *positions, uint32_t n_verts, const uint32_t *indices, uint32_t n_tris,
+                        const float *tri_colors);
+
+/* Copies the current mesh back in ar_set_mesh's layout (each pointer may be NULL); n_verts / n_tris receive
+ * its size.  Counterpart of reading back the buffers given to gl.bufferData (raster.js:238-251); lets a
+ * caller check or keep what ar_set_mesh_indexed built. */
+int ar_read_mesh(ar_ctx *ctx, float *vbo9, uint32_t *idx, uint32_t *n_verts, uint32_t *n_tris);
+
 /* Integer texel coordinates for atlas texturing, one row of eight u16 per triangle of the current mesh:
  * (u0, v0, u1, v1, u2, v2, flags, 0) - the uvA/uvB/uvC of scene tris and the uv0..uv3 of quads as
  * SceneBuilder stores them (js/render/scene_api.js:139-160) and the path tracer uploads them

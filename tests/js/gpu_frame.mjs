@@ -92,6 +92,9 @@ const dump = (name, ta) => fs.writeFileSync(path.join(outDir, name), Buffer.from
     if (!(pfb instanceof Uint8ClampedArray) || pfb.length !== 640 * 360 * 4) throw new Error('allocFramebuffer shape');
     direct.render(0.0, pfb, { cols: 640, rows: 360 });
     if (Buffer.compare(Buffer.from(pfb.buffer, pfb.byteOffset, pfb.length), Buffer.from(f2.fb.buffer)) !== 0) throw new Error('pinned framebuffer differs');
+    // typed-array scenes have their vertex buffer built on the GPU: it must equal the host-side build byte for byte
+    const built = direct.readMesh(), wantMesh = (await import(path.join(JS, 'hip_backend.js'))).meshToVbo(ico.positions, ico.indices, null);
+    if (Buffer.compare(Buffer.from(built.vbo.buffer), Buffer.from(wantMesh.vbo.buffer)) !== 0 || Buffer.compare(Buffer.from(built.idx.buffer), Buffer.from(wantMesh.idx.buffer)) !== 0) throw new Error('device-built vertex buffer differs from meshToVbo');
     const back = direct.getPixels({});
     if (back[0] !== pfb[(359 * 640) * 4]) throw new Error('getPixels after a pinned render');
     direct.dispose();

@@ -224,6 +224,47 @@ def test_texture_argument_errors(pkg, R):
     R.set_texture(None)
 
 
+def test_indexed_mesh_is_built_on_the_gpu_byte_for_byte(pkg, oracle, R):
+    """ar_set_mesh_indexed against the host's vectorised pushTri (host.mesh_to_vbo, itself checked against
+    the reference's recorded VBOs): shared-vertex meshes, per-triangle colours, degenerate triangles
+    (normal (0, 1, 0)), an index beyond the vertex array (NaN positions, triangle invisible)."""
+    def same(P, I, C):
+        want_v, want_i = pkg.host.mesh_to_vbo(P, I, C)
+        R.set_mesh_indexed(P, I, C)
+        got_v, got_i = R.read_mesh()
+        assert np.array_equal(got_i, want_i)
+        assert np.array_equal(got_v.view(np.uint32), want_v.view(np.uint32)), np.count_nonzero(got_v.view(np.uint32) != want_v.view(np.uint32))
+        return want_v, want_i
+
+    same(*pkg.geometry.cube(0.5), None)
+    same(*pkg.geometry.icosphere(5, 1.0), None)
+    P, I, C = pkg.geometry.random_mesh(0xA5C11, 300_000, 1920, 1080, 1.0)
+    vbo, idx = same(P, I, C)
+    # the frame from the device-built mesh is the frame from the uploaded one
+    sc = pkg.scenes.random_scene(300_000, 640, 360)
+    assert np.array_equal(sc["vbo"].view(np.uint32), vbo.view(np.uint32))
+    R.set_camera(sc["proj"], sc["view"]); R.set_lights(sc["lights"]); R.set_ascii("@%#*+=-:. ", True, 2, 12)
+    a = R.render(640, 360, want_ids=True)
+    pkg.scenes.upload(R, sc)
+    b = R.render(640, 360, want_ids=True)
+    for k in ("rgba", "depth", "ascii", "ids"):
+        assert np.array_equal(a[k], b[k]), k
+    # degenerate and tiny triangles, shared vertices, one bad index
+    P = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1e-5, 0, 0], [0, 1e-5, 0], [2, 2, 2], [3e-3, 1e-3, 0]], dtype=np.float32)
+    I = np.array([[0, 1, 2], [5, 5, 5], [0, 3, 4], [0, 1, 1], [2, 1, 0], [0, 6, 3], [0, 1, 7]], dtype=np.uint32)
+    want_v, want_i = pkg.host.mesh_to_vbo(np.vstack([P, [[np.nan] * 3]]).astype(np.float32), I, None)
+    R.set_mesh_indexed(P, I)
+    got_v, got_i = R.read_mesh()
+    assert np.array_equal(got_i, want_i)
+    ok = ~np.isnan(want_v)
+    assert np.array_equal(np.isnan(got_v), ~ok) and np.array_equal(got_v[ok].view(np.uint32), want_v[ok].view(np.uint32))
+    assert got_v[3, 3:6].tolist() == [0.0, 1.0, 0.0] and got_v[6, 3:6].tolist() == [0.0, 1.0, 0.0]
+    with pytest.raises(pkg.AsciiRastError):
+        R._check(R._L.ar_set_mesh_indexed(R._h, None, 0, None, 3, None))
+    R.set_mesh_indexed(np.zeros((0, 3), dtype=np.float32), np.zeros((0, 3), dtype=np.uint32))
+    assert R.read_mesh()[1].size == 0
+
+
 def test_pool_overflow_falls_back_and_stays_exact(pkg, oracle):
     """A record pool far too small for the frame: some binning workgroups must resolve through the
     global key buffer, and the merged result is still bit-exact - also on the following frames."""
