@@ -9,19 +9,32 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libascii_rast.so")
-N_KERNELS = 12
+N_KERNELS = 13
 EXPORTS = [
     "ar_create", "ar_destroy", "ar_last_error", "ar_set_mesh", "ar_set_camera", "ar_set_lights",
     "ar_set_ascii", "ar_set_strip", "ar_set_id_output", "ar_render", "ar_render_async", "ar_sync", "ar_read",
     "ar_device_buffer", "ar_stream", "ar_host_alloc", "ar_host_free", "ar_stream_wait_frame", "ar_frame_wait_stream", "ar_set_stream",
     "ar_set_ascii_target", "ar_quantize", "ar_quantize_colors", "ar_read_colors", "ar_present", "ar_set_profiling", "ar_kernel_stats",
     "ar_frame_counters", "ar_set_option", "ar_set_mesh_uv", "ar_set_texture", "ar_set_mesh_indexed", "ar_read_mesh",
+    "ar_rt_set_scene", "ar_rt_render", "ar_rt_render_async",
 ]
 _lib = None
 
 _fp = ctypes.POINTER(ctypes.c_float)
 _u8p = ctypes.POINTER(ctypes.c_uint8)
 _u32p = ctypes.POINTER(ctypes.c_uint32)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+
+
+class RtScene(ctypes.Structure):
+    """ar_rt_scene of include/ascii_rast.h."""
+    _fields_ = [("n_spheres", ctypes.c_int), ("spheres4", _fp), ("sphere_mat", _i32p),
+                ("n_planes", ctypes.c_int), ("planes4", _fp), ("plane_mat", _i32p),
+                ("n_tris", ctypes.c_int), ("tri_a", _fp), ("tri_b", _fp), ("tri_c", _fp), ("tri_mat", _i32p),
+                ("n_mats", ctypes.c_int), ("mat_albedo", _fp), ("mat_reflective", _i32p),
+                ("n_pl", ctypes.c_int), ("pl_pos", _fp), ("pl_col", _fp),
+                ("n_dl", ctypes.c_int), ("dl_dir", _fp), ("dl_col", _fp),
+                ("env", ctypes.c_float * 3)]
 
 
 class AsciiRastError(RuntimeError):
@@ -46,6 +59,9 @@ def load_library():
     L.ar_last_error.argtypes = [vp]
     L.ar_last_error.restype = ctypes.c_char_p
     L.ar_set_mesh.argtypes = [vp, _fp, ctypes.c_uint32, _u32p, ctypes.c_uint32]
+    L.ar_rt_set_scene.argtypes = [vp, ctypes.POINTER(RtScene)]
+    L.ar_rt_render.argtypes = [vp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _u8p, _u8p]
+    L.ar_rt_render_async.argtypes = [vp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float]
     L.ar_set_mesh_indexed.argtypes = [vp, _fp, ctypes.c_uint32, _u32p, ctypes.c_uint32, _fp]
     L.ar_read_mesh.argtypes = [vp, _fp, _u32p, _u32p, _u32p]
     L.ar_set_mesh_uv.argtypes = [vp, ctypes.POINTER(ctypes.c_uint16), ctypes.c_uint32]
@@ -82,7 +98,8 @@ def load_library():
     L.ar_set_option.argtypes = [vp, ctypes.c_int, ctypes.c_longlong]
     for name in ("ar_set_id_output", "ar_set_mesh", "ar_set_camera", "ar_set_lights", "ar_set_ascii", "ar_set_strip", "ar_set_id_output", "ar_render",
                  "ar_render_async", "ar_sync", "ar_read", "ar_quantize", "ar_stream_wait_frame", "ar_frame_wait_stream", "ar_set_stream", "ar_set_ascii_target", "ar_quantize_colors", "ar_read_colors", "ar_present", "ar_set_profiling", "ar_kernel_stats",
-                 "ar_frame_counters", "ar_set_option", "ar_set_mesh_uv", "ar_set_texture", "ar_set_mesh_indexed", "ar_read_mesh"):
+                 "ar_frame_counters", "ar_set_option", "ar_set_mesh_uv", "ar_set_texture", "ar_set_mesh_indexed", "ar_read_mesh", "ar_rt_set_scene", "ar_rt_render",
+                 "ar_rt_render_async"):
         getattr(L, name).restype = ctypes.c_int
     _lib = L
     return L
@@ -148,6 +165,42 @@ class Renderer:
         if nt.value:
             self._check(self._L.ar_read_mesh(self._h, vbo.ctypes.data_as(_fp), idx.ctypes.data_as(_u32p), None, None))
         return vbo, idx
+
+    def rt_set_scene(self, u):
+        """Ray backend scene from the uniform arrays RaytraceBackend uploads (raytrace.js:351-389): dict with
+        uNumS, uSpheres (float [n, 4]), uSm (int), uNumP, uPlanes, uPm, uNumT, uTa, uTb, uTc, uTm, uNumMats,
+        uMatAlbedo, uMatReflective, uNumPL, uPLPos, uPLCol, uNumDL, uDLDir, uDLCol, uEnv; absent arrays count as empty."""
+        keep, sc = [], RtScene()
+
+        def arr(key, dtype, ptr):
+            a = np.ascontiguousarray(u.get(key, np.zeros(0)), dtype=dtype).reshape(-1)
+            keep.append(a)
+            return a.ctypes.data_as(ptr) if a.size else None
+
+        sc.n_spheres, sc.spheres4, sc.sphere_mat = int(u.get("uNumS", 0)), arr("uSpheres", np.float32, _fp), arr("uSm", np.int32, _i32p)
+        sc.n_planes, sc.planes4, sc.plane_mat = int(u.get("uNumP", 0)), arr("uPlanes", np.float32, _fp), arr("uPm", np.int32, _i32p)
+        sc.n_tris, sc.tri_a, sc.tri_b, sc.tri_c = int(u.get("uNumT", 0)), arr("uTa", np.float32, _fp), arr("uTb", np.float32, _fp), arr("uTc", np.float32, _fp)
+        sc.tri_mat = arr("uTm", np.int32, _i32p)
+        sc.n_mats, sc.mat_albedo, sc.mat_reflective = int(u.get("uNumMats", 0)), arr("uMatAlbedo", np.float32, _fp), arr("uMatReflective", np.int32, _i32p)
+        sc.n_pl, sc.pl_pos, sc.pl_col = int(u.get("uNumPL", 0)), arr("uPLPos", np.float32, _fp), arr("uPLCol", np.float32, _fp)
+        sc.n_dl, sc.dl_dir, sc.dl_col = int(u.get("uNumDL", 0)), arr("uDLDir", np.float32, _fp), arr("uDLCol", np.float32, _fp)
+        env = np.asarray(u.get("uEnv", (0, 0, 0)), dtype=np.float32).reshape(-1)
+        sc.env = (ctypes.c_float * 3)(*[float(x) for x in env[:3]])
+        self._check(self._L.ar_rt_set_scene(self._h, ctypes.byref(sc)))
+
+    def rt_render(self, cols, rows, cam_pos, yaw, pitch, fovy, pix_aspect=1.0):
+        """One frame of the ray backend -> dict(rgba [rows, cols, 4], ascii [rows, cols])."""
+        _c, cp = _f32(cam_pos)
+        rgba = np.zeros((rows, cols, 4), dtype=np.uint8)
+        ascii_ = np.zeros((rows, cols), dtype=np.uint8)
+        self._check(self._L.ar_rt_render(self._h, cols, rows, cp, yaw, pitch, fovy, pix_aspect,
+                                         rgba.ctypes.data_as(_u8p), ascii_.ctypes.data_as(_u8p)))
+        return {"rgba": rgba, "ascii": ascii_}
+
+    def rt_render_async(self, cols, rows, cam_pos, yaw, pitch, fovy, pix_aspect=1.0):
+        _c, cp = _f32(cam_pos)
+        self._check(self._L.ar_rt_render_async(self._h, cols, rows, cp, yaw, pitch, fovy, pix_aspect))
+        self.cols, self.rows = cols, rows
 
     def set_mesh_uv(self, uv8):
         """uv8: uint16 [n_tris, 8] rows (u0, v0, u1, v1, u2, v2, flags, 0) for the current mesh, or None to remove."""

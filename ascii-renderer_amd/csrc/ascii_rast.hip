@@ -39,10 +39,11 @@ constexpr int kMediumMaxCells = 4096;   // above this a record goes to the per-c
 constexpr uint32_t kMediumCapacity = 1u << 18;
 constexpr uint32_t kLargeCapacity = 1u << 14;
 
-enum KernelSlot { K_CLEAR = 0, K_RASTER, K_MEDIUM, K_LARGE, K_SHADE, K_ASCII, K_SETUP, K_BINSCAN, K_BINOFF, K_FILL, K_TILE, K_PRESENT };
+enum KernelSlot { K_CLEAR = 0, K_RASTER, K_MEDIUM, K_LARGE, K_SHADE, K_ASCII, K_SETUP, K_BINSCAN, K_BINOFF, K_FILL, K_TILE, K_PRESENT, K_RAYTRACE };
 const char *const kKernelNames[AR_N_KERNELS] = {"k_clear",  "k_raster", "k_raster_medium", "k_raster_large",
                                                 "k_shade", "k_ascii",  "k_setup",         "k_binscan",
-                                                "k_binoffsets", "k_fill", "k_tile", "k_present"};
+                                                "k_binoffsets", "k_fill", "k_tile", "k_present",
+                                                "k_raytrace"};
 
 // Everything a frame's kernels need besides the big buffers; passed by value as a kernel argument.
 struct FrameParams {
@@ -1478,6 +1479,205 @@ void launch_ascii(const FrameParams &fp, const void *src, uint8_t *ascii, hipStr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ray backend: the reference's deterministic single-bounce ray tracer (raytrace_shader.js:62-242) as one
+// kernel, a lane per cell.  Binary32 throughout, no fused multiply-add, expressions left to right;
+// normalize(v) = v * (1 / sqrt(dot(v, v))) with the zero vector staying zero, reflect(I, N) =
+// I - (2 dot(N, I)) N, max / min = fmaxf / fminf.  The scene arrays are read at addresses that are the same
+// for every lane (scalar loads); only the hit tests diverge.
+// ------------------------------------------------------------------------------------------------
+struct RtScene {  // device pointers into one allocation; counts as uploaded by raytrace.js:351-389
+    int n_spheres, n_planes, n_tris, n_mats, n_pl, n_dl;
+    const float *spheres4, *planes4, *tri_a, *tri_b, *tri_c, *mat_albedo, *pl_pos, *pl_col, *dl_dir, *dl_col;
+    const int32_t *sphere_mat, *plane_mat, *tri_mat, *mat_reflective;
+    float env[3];
+};
+
+struct RtCamera {  // per-frame terms of raytrace_shader.js:200-210, evaluated on the host
+    float ro[3], uu[3], vv[3], ww[3];
+    float focal, aspect;  // aspect = (cols / rows) * max(pixel aspect, 1e-6)
+};
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 vload(const float *p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float vdot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ V3 vcross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ V3 vnorm(V3 a) {
+    const float d = vdot(a, a);
+    return d > 0.0f ? a * (1.0f / sqrtf(d)) : V3{0.0f, 0.0f, 0.0f};
+}
+
+constexpr float kRtEps = 1e-4f, kRtFar = 1e6f;
+
+__device__ __forceinline__ float rt_sphere(V3 ro, V3 rd, const float *s) {  // raytrace_shader.js:89-101
+    const V3 oc = ro - vload(s);
+    const float b = vdot(oc, rd);
+    const float c = vdot(oc, oc) - s[3] * s[3];
+    const float h = b * b - c;
+    if (h < 0.0f) return -1.0f;
+    const float q = sqrtf(h);
+    const float t1 = -b - q, t2 = -b + q;
+    if (t1 > kRtEps) return t1;
+    if (t2 > kRtEps) return t2;
+    return -1.0f;
+}
+
+__device__ __forceinline__ float rt_plane(V3 ro, V3 rd, const float *pl) {  // :104-109
+    const V3 n = vload(pl);
+    const float denom = vdot(n, rd);
+    if (fabsf(denom) < 1e-6f) return -1.0f;
+    const float t = (-pl[3] - vdot(n, ro)) / denom;
+    return t > kRtEps ? t : -1.0f;
+}
+
+__device__ __forceinline__ float rt_tri(V3 ro, V3 rd, V3 a, V3 b, V3 c, V3 &n) {  // :111-125
+    const V3 e1 = b - a, e2 = c - a;
+    const V3 p = vcross(rd, e2);
+    const float det = vdot(e1, p);
+    n = v3(0.0f, 0.0f, 0.0f);
+    if (fabsf(det) < 1e-6f) return -1.0f;
+    const float inv = 1.0f / det;
+    const V3 t = ro - a;
+    const float u = vdot(t, p) * inv;
+    if (u < 0.0f || u > 1.0f) return -1.0f;
+    const V3 q = vcross(t, e1);
+    const float v = vdot(rd, q) * inv;
+    if (v < 0.0f || u + v > 1.0f) return -1.0f;
+    const float tt = vdot(e2, q) * inv;
+    if (tt <= kRtEps) return -1.0f;
+    n = vnorm(vcross(e1, e2));
+    if (vdot(n, rd) > 0.0f) n = v3(-n.x, -n.y, -n.z);
+    return tt;
+}
+
+struct RtHit { float t; int m; V3 n; };
+
+__device__ __forceinline__ RtHit rt_intersect(const RtScene &S, V3 ro, V3 rd) {  // :129-150
+    RtHit H{kRtFar, -1, V3{0.0f, 0.0f, 0.0f}};
+    for (int i = 0; i < S.n_spheres; i++) {
+        const float *s = S.spheres4 + 4 * i;
+        const float t = rt_sphere(ro, rd, s);
+        if (t > kRtEps && t < H.t) {
+            H.t = t; H.m = S.sphere_mat[i];
+            const V3 pos = ro + rd * t;
+            const float r = fmaxf(s[3], 1e-6f);
+            const V3 d = pos - vload(s);
+            H.n = v3(d.x / r, d.y / r, d.z / r);
+        }
+    }
+    for (int i = 0; i < S.n_planes; i++) {
+        const float t = rt_plane(ro, rd, S.planes4 + 4 * i);
+        if (t > kRtEps && t < H.t) { H.t = t; H.m = S.plane_mat[i]; H.n = vload(S.planes4 + 4 * i); }
+    }
+    for (int i = 0; i < S.n_tris; i++) {
+        V3 n;
+        const float t = rt_tri(ro, rd, vload(S.tri_a + 3 * i), vload(S.tri_b + 3 * i), vload(S.tri_c + 3 * i), n);
+        if (t > kRtEps && t < H.t) { H.t = t; H.m = S.tri_mat[i]; H.n = n; }
+    }
+    return H;
+}
+
+__device__ __forceinline__ bool rt_occluded(const RtScene &S, V3 ro, V3 rd, float max_t) {  // :152-166: no planes
+    for (int i = 0; i < S.n_spheres; i++) {
+        const float t = rt_sphere(ro, rd, S.spheres4 + 4 * i);
+        if (t > kRtEps && t < max_t) return true;
+    }
+    for (int i = 0; i < S.n_tris; i++) {
+        V3 n;
+        const float t = rt_tri(ro, rd, vload(S.tri_a + 3 * i), vload(S.tri_b + 3 * i), vload(S.tri_c + 3 * i), n);
+        if (t > kRtEps && t < max_t) return true;
+    }
+    return false;
+}
+
+__device__ __forceinline__ V3 rt_shade_diffuse(const RtScene &S, V3 pos, V3 N, V3 albedo) {  // :168-196
+    const float z = fmaxf(N.y * 0.0f, 0.0f);
+    V3 Lo = v3(S.env[0] * z, S.env[1] * z, S.env[2] * z);
+    const V3 org = pos + N * kRtEps;
+    for (int i = 0; i < S.n_dl; i++) {
+        const V3 d = vload(S.dl_dir + 3 * i);
+        const V3 L = vnorm(v3(-d.x, -d.y, -d.z));
+        const float ndl = fmaxf(vdot(N, L), 0.0f);
+        if (ndl > 0.0f && !rt_occluded(S, org, L, 1e5f)) {
+            const float *c = S.dl_col + 3 * i;
+            Lo = v3(Lo.x + (albedo.x * c[0]) * ndl, Lo.y + (albedo.y * c[1]) * ndl, Lo.z + (albedo.z * c[2]) * ndl);
+        }
+    }
+    for (int i = 0; i < S.n_pl; i++) {
+        const V3 Lv = vload(S.pl_pos + 3 * i) - pos;
+        const float dist2 = fmaxf(vdot(Lv, Lv), 1e-6f);
+        const V3 L = Lv * (1.0f / sqrtf(dist2));
+        const float ndl = fmaxf(vdot(N, L), 0.0f);
+        if (ndl > 0.0f && !rt_occluded(S, org, L, sqrtf(dist2) - 2.0f * kRtEps)) {
+            const float att = 1.0f / (1.0f + dist2 * 0.05f);
+            const float w = ndl * att;
+            const float *c = S.pl_col + 3 * i;
+            Lo = v3(Lo.x + (albedo.x * c[0]) * w, Lo.y + (albedo.y * c[1]) * w, Lo.z + (albedo.z * c[2]) * w);
+        }
+    }
+    return Lo;
+}
+
+__device__ __forceinline__ void rt_material(const RtScene &S, int m, V3 &albedo, bool &reflective) {  // :71-86,218-220
+    const int mi = int(fminf(fmaxf(float(m), 0.0f), float(S.n_mats - 1)));
+    albedo = v3(0.8f, 0.8f, 0.8f);
+    reflective = false;
+    if (mi >= 0 && mi < S.n_mats) { albedo = vload(S.mat_albedo + 3 * mi); reflective = S.mat_reflective[mi] != 0; }
+}
+
+// One lane per cell of output rows [ya, yb): primary ray, nearest hit, direct light with hard shadows, or one
+// mirror bounce (raytrace_shader.js:198-242).  RGBA8, alpha 255, row 0 = top.
+__global__ __launch_bounds__(256) void k_raytrace(RtScene S, RtCamera cam, int cols, int rows, int ya, int yb,
+                                                  uint32_t *__restrict__ rgba) {
+    const size_t n = size_t(yb - ya) * cols;
+    const size_t p = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p >= n) return;
+    const int r = ya + int(p / size_t(cols)), i = int(p % size_t(cols));
+    const int j = rows - 1 - r;  // GL window row
+    float px = -1.0f + 2.0f * ((float(i) + 0.5f) / float(cols));
+    const float py = -1.0f + 2.0f * ((float(j) + 0.5f) / float(rows));
+    px = px * cam.aspect;
+    const V3 ro = vload(cam.ro), uu = vload(cam.uu), vv = vload(cam.vv), ww = vload(cam.ww);
+    const V3 rd = vnorm(v3((px * uu.x + py * vv.x) + cam.focal * ww.x, (px * uu.y + py * vv.y) + cam.focal * ww.y,
+                           (px * uu.z + py * vv.z) + cam.focal * ww.z));
+    V3 col;
+    const RtHit H = rt_intersect(S, ro, rd);
+    if (H.m < 0) {
+        col = vload(S.env);
+    } else {
+        const V3 hit = ro + rd * H.t;
+        const V3 N = vnorm(H.n);
+        V3 albedo; bool refl;
+        rt_material(S, H.m, albedo, refl);
+        if (!refl) {
+            col = rt_shade_diffuse(S, hit, N, albedo);
+        } else {
+            const float d2 = 2.0f * vdot(N, rd);
+            const V3 rdir = rd - N * d2;
+            const V3 org = hit + N * kRtEps;
+            const RtHit H2 = rt_intersect(S, org, rdir);
+            if (H2.m < 0) {
+                col = vload(S.env);
+            } else {
+                const V3 hit2 = org + rdir * H2.t;
+                const V3 N2 = vnorm(H2.n);
+                V3 alb2; bool r2;
+                rt_material(S, H2.m, alb2, r2);
+                col = rt_shade_diffuse(S, hit2, N2, alb2);
+            }
+        }
+    }
+    const float c3[3] = {col.x, col.y, col.z};
+    uint32_t out = 0xFF000000u;
+#pragma unroll
+    for (int k = 0; k < 3; k++) out |= uint32_t(int(floorf(fminf(fmaxf(c3[k], 0.0f), 1.0f) * 255.0f + 0.5f))) << (8 * k);
+    rgba[size_t(r) * cols + i] = out;
+}
+
 thread_local char g_create_error[256] = "";
 
 }  // namespace
@@ -1523,6 +1723,9 @@ struct ar_ctx {
     // everything the binning kernels write, per buffer set
     BinRec *d_records[kSets] = {};  // 2 x n_tris setup record slots, filled densely per k_setup workgroup
     uint8_t *d_flat = nullptr;       // n_tris flag bytes: kFlagFlat | kFlagTextured
+    void *d_rt = nullptr;            // ray backend: the scene arrays of ar_rt_set_scene in one allocation
+    RtScene rt_scene = {};           // counts and device pointers into d_rt
+    bool rt_has_scene = false;
     uint4 *d_triuv = nullptr;        // n_tris texel-coordinate rows (ar_set_mesh_uv), else null
     uint32_t *d_atlas = nullptr;     // atlas texels (ar_set_texture), else null
     int atlas_w = 0, atlas_h = 0;
@@ -1914,7 +2117,7 @@ void ar_destroy(ar_ctx *ctx) {
     (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii); (void)hipFree(ctx->d_q_colors);
     (void)hipFree(ctx->d_p_atlas); (void)hipFree(ctx->d_p_cov); (void)hipFree(ctx->d_p_image);
     (void)hipFree(ctx->d_state); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr); (void)hipFree(ctx->d_flat);
-    (void)hipFree(ctx->d_triuv); (void)hipFree(ctx->d_atlas);
+    (void)hipFree(ctx->d_triuv); (void)hipFree(ctx->d_atlas); (void)hipFree(ctx->d_rt);
     for (int k = 0; k < kSets; k++) {
         (void)hipFree(ctx->d_entries[k]); (void)hipFree(ctx->d_surv[k]); (void)hipFree(ctx->d_surv_count[k]);
         (void)hipFree(ctx->d_dircount[k]); (void)hipFree(ctx->d_records[k]);
@@ -2208,6 +2411,129 @@ int ar_quantize(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *a
     AR_HIP(ctx, hipMemcpyAsync(ascii, ctx->d_q_ascii, size_t(cols) * rows, hipMemcpyDeviceToHost, ctx->stream));
     AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
+}
+
+int ar_rt_set_scene(ar_ctx *ctx, const ar_rt_scene *sc) {
+    if (!ctx) return AR_E_ARG;
+    if (!sc) return fail(ctx, AR_E_ARG, "ar_rt_set_scene: null scene");
+    const int counts[6] = {sc->n_spheres, sc->n_planes, sc->n_tris, sc->n_mats, sc->n_pl, sc->n_dl};
+    for (int c : counts)
+        if (c < 0 || c > 65536) return fail(ctx, AR_E_ARG, "ar_rt_set_scene: count %d out of range", c);
+    if ((sc->n_spheres && (!sc->spheres4 || !sc->sphere_mat)) || (sc->n_planes && (!sc->planes4 || !sc->plane_mat)) ||
+        (sc->n_tris && (!sc->tri_a || !sc->tri_b || !sc->tri_c || !sc->tri_mat)) || (sc->n_mats && (!sc->mat_albedo || !sc->mat_reflective)) ||
+        (sc->n_pl && (!sc->pl_pos || !sc->pl_col)) || (sc->n_dl && (!sc->dl_dir || !sc->dl_col)))
+        return fail(ctx, AR_E_ARG, "ar_rt_set_scene: null array with a non-zero count");
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = sync_streams(ctx);
+    if (rc) return rc;
+    // one host image of all arrays (4-byte elements), one allocation, one copy
+    std::vector<uint32_t> blob;
+    auto put = [&](const void *src, size_t words) {
+        const size_t at = blob.size();
+        blob.resize(at + (words ? words : 1));
+        if (words) memcpy(blob.data() + at, src, words * 4);
+        return at;
+    };
+    const size_t o_s4 = put(sc->spheres4, size_t(sc->n_spheres) * 4), o_sm = put(sc->sphere_mat, size_t(sc->n_spheres));
+    const size_t o_p4 = put(sc->planes4, size_t(sc->n_planes) * 4), o_pm = put(sc->plane_mat, size_t(sc->n_planes));
+    const size_t o_ta = put(sc->tri_a, size_t(sc->n_tris) * 3), o_tb = put(sc->tri_b, size_t(sc->n_tris) * 3);
+    const size_t o_tc = put(sc->tri_c, size_t(sc->n_tris) * 3), o_tm = put(sc->tri_mat, size_t(sc->n_tris));
+    const size_t o_ma = put(sc->mat_albedo, size_t(sc->n_mats) * 3), o_mr = put(sc->mat_reflective, size_t(sc->n_mats));
+    const size_t o_pp = put(sc->pl_pos, size_t(sc->n_pl) * 3), o_pc = put(sc->pl_col, size_t(sc->n_pl) * 3);
+    const size_t o_dd = put(sc->dl_dir, size_t(sc->n_dl) * 3), o_dc = put(sc->dl_col, size_t(sc->n_dl) * 3);
+    (void)hipFree(ctx->d_rt);
+    ctx->d_rt = nullptr;
+    ctx->rt_has_scene = false;
+    AR_HIP(ctx, hipMalloc(&ctx->d_rt, blob.size() * 4));
+    AR_HIP(ctx, hipMemcpy(ctx->d_rt, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
+    const float *f = static_cast<const float *>(ctx->d_rt);
+    const int32_t *w = static_cast<const int32_t *>(ctx->d_rt);
+    RtScene &S = ctx->rt_scene;
+    S.n_spheres = sc->n_spheres; S.n_planes = sc->n_planes; S.n_tris = sc->n_tris; S.n_mats = sc->n_mats; S.n_pl = sc->n_pl; S.n_dl = sc->n_dl;
+    S.spheres4 = f + o_s4; S.sphere_mat = w + o_sm; S.planes4 = f + o_p4; S.plane_mat = w + o_pm;
+    S.tri_a = f + o_ta; S.tri_b = f + o_tb; S.tri_c = f + o_tc; S.tri_mat = w + o_tm;
+    S.mat_albedo = f + o_ma; S.mat_reflective = w + o_mr;
+    S.pl_pos = f + o_pp; S.pl_col = f + o_pc; S.dl_dir = f + o_dd; S.dl_col = f + o_dc;
+    for (int k = 0; k < 3; k++) S.env[k] = sc->env[k];
+    ctx->rt_has_scene = true;
+    return 0;
+}
+
+int ar_rt_render_async(ar_ctx *ctx, int cols, int rows, const float cam_pos[3], float yaw, float pitch, float fovy, float pix_aspect) {
+    if (!ctx) return AR_E_ARG;
+    if (!cam_pos || cols <= 0 || rows <= 0 || size_t(cols) * rows > (size_t(1) << 31))
+        return fail(ctx, AR_E_ARG, "ar_rt_render: bad arguments (%d x %d)", cols, rows);
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_targets(ctx, cols, rows);
+    if (rc) return rc;
+    if (!ctx->rt_has_scene) return 0;  // raytrace.js:321: no scene, nothing drawn
+    if (ctx->overlapped_in_flight) {   // raster frames may still be writing output set 0
+        rc = sync_streams(ctx);
+        if (rc) return rc;
+    }
+    FrameParams fp = ctx->fp;
+    fp.cols = cols; fp.rows = rows;
+    int row0 = 0, row1 = rows;
+    if (ctx->strip1 > ctx->strip0) {
+        if (ctx->strip1 > rows) return fail(ctx, AR_E_ARG, "strip [%d,%d) exceeds %d rows", ctx->strip0, ctx->strip1, rows);
+        row0 = ctx->strip0; row1 = ctx->strip1;
+    }
+    const int halo = fp.mode_on == 1 ? 3 : 0;
+    fp.row0 = row0; fp.row1 = row1;
+    fp.ya = row0 - halo < 0 ? 0 : row0 - halo;
+    fp.yb = row1 + halo > rows ? rows : row1 + halo;
+    // camera terms of raytrace_shader.js:66-70,203-207: binary64 libm on the binary32 uniforms, rounded once
+    RtCamera cam;
+    const double cp = std::cos(double(pitch)), sp = std::sin(double(pitch)), cy = std::cos(double(yaw)), sy = std::sin(double(yaw));
+    auto dot3 = [](const float *a, const float *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; };
+    auto norm3 = [&](float *v) {
+        const float d = dot3(v, v);
+        const float k = d > 0.0f ? 1.0f / std::sqrt(d) : 0.0f;
+        if (d > 0.0f) { v[0] = v[0] * k; v[1] = v[1] * k; v[2] = v[2] * k; } else { v[0] = v[1] = v[2] = 0.0f; }
+    };
+    auto cross3 = [](const float *a, const float *b, float *o) {
+        o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    cam.ww[0] = float(cp * cy); cam.ww[1] = float(sp); cam.ww[2] = float(cp * sy);
+    norm3(cam.ww);
+    const float up[3] = {0.0f, 1.0f, 0.0f};
+    cross3(cam.ww, up, cam.uu);
+    norm3(cam.uu);
+    if (std::sqrt(dot3(cam.uu, cam.uu)) < 1e-3f) { cam.uu[0] = 1.0f; cam.uu[1] = 0.0f; cam.uu[2] = 0.0f; }
+    cross3(cam.uu, cam.ww, cam.vv);
+    norm3(cam.vv);
+    cam.focal = 1.0f / std::fmax(1e-6f, float(std::tan(0.5 * double(fovy))));
+    cam.aspect = (float(cols) / float(rows)) * std::fmax(pix_aspect, 1e-6f);
+    for (int k = 0; k < 3; k++) cam.ro[k] = cam_pos[k];
+    const size_t strip_cells = size_t(fp.yb - fp.ya) * cols;
+    uint8_t *ascii_out = ctx->ascii_target ? ctx->ascii_target - ptrdiff_t(ctx->target_row) * cols : ctx->d_ascii[0];
+    {
+        Stamper s(ctx, K_RAYTRACE);
+        k_raytrace<<<unsigned((strip_cells + 255) / 256), 256, 0, ctx->stream>>>(ctx->rt_scene, cam, cols, rows, fp.ya, fp.yb,
+                                                                               reinterpret_cast<uint32_t *>(ctx->d_rgba[0]));
+    }
+    {
+        Stamper s(ctx, K_ASCII);
+        if (fp.mode_on == 1) {
+            launch_ascii<true>(fp, ctx->d_rgba[0], ascii_out, ctx->stream);
+        } else {
+            const size_t first = size_t(row0) * cols, n = size_t(row1 - row0) * cols;
+            k_quantize_plain<<<unsigned((n + 255) / 256), 256, 0, ctx->stream>>>(
+                fp, reinterpret_cast<const uint32_t *>(ctx->d_rgba[0]) + first, ascii_out + first, n);
+        }
+    }
+    AR_HIP(ctx, hipGetLastError());
+    ctx->rendered = true;
+    ctx->last_oset = 0;
+    return 0;
+}
+
+int ar_rt_render(ar_ctx *ctx, int cols, int rows, const float cam_pos[3], float yaw, float pitch, float fovy, float pix_aspect,
+                 uint8_t *rgba, uint8_t *ascii) {
+    int rc = ar_rt_render_async(ctx, cols, rows, cam_pos, yaw, pitch, fovy, pix_aspect);
+    if (rc) return rc;
+    if (!ctx->rt_has_scene) return 0;
+    return ar_read(ctx, rgba, nullptr, ascii, nullptr);
 }
 
 int ar_present(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, const uint8_t *atlas_alpha, int cell_w, int cell_h,

@@ -185,10 +185,44 @@ int ar_present(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, const uint8
 int ar_quantize_colors(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, int steps, int grayscale, uint32_t *colors);
 int ar_read_colors(ar_ctx *ctx, int steps, int grayscale, uint32_t *colors);
 
+/* ---- ray backend -----------------------------------------------------------------------------------
+ * The reference's deterministic single-bounce ray tracer (js/render/backends/raytrace.js,
+ * raytrace_shader.js) behind the same context: spheres, planes and triangles, diffuse or mirror materials,
+ * point and directional lights with hard shadows, one mirror bounce, environment colour on a miss. */
+typedef struct ar_rt_scene {   /* the uniform arrays RaytraceBackend._packScene builds (raytrace.js:195-311) */
+    int n_spheres; const float *spheres4;   const int32_t *sphere_mat;     /* uNumS, uSpheres (xyz, r), uSm */
+    int n_planes;  const float *planes4;    const int32_t *plane_mat;      /* uNumP, uPlanes (n, d), uPm */
+    int n_tris;    const float *tri_a, *tri_b, *tri_c; const int32_t *tri_mat; /* uNumT, uTa, uTb, uTc, uTm */
+    int n_mats;    const float *mat_albedo; const int32_t *mat_reflective; /* uNumMats, uMatAlbedo, uMatReflective */
+    int n_pl;      const float *pl_pos, *pl_col;                           /* uNumPL, uPLPos, uPLCol */
+    int n_dl;      const float *dl_dir, *dl_col;                           /* uNumDL, uDLDir, uDLCol */
+    float env[3];                                                          /* uEnv */
+} ar_rt_scene;
+
+/* Replaces the scene uniform uploads of RaytraceBackend.render (raytrace.js:349-389).  Arrays hold exactly
+ * n_* entries (3 or 4 floats each as in the shader's declarations); they are copied.  A material index
+ * below zero makes its primitive count as a miss, indices beyond the table clamp to its last entry, an empty
+ * table means albedo 0.8 diffuse (raytrace_shader.js:71-86,214-220). */
+int ar_rt_set_scene(ar_ctx *ctx, const ar_rt_scene *scene);
+
+/* Renders one frame of the ray backend at cols x rows cells and blocks until done.
+ * Replaces: RaytraceBackend.render from the camera uniforms to readPixels + flipAndCopy (raytrace.js:330-402)
+ * plus the index half of AsciiPass.draw, as ar_render does for the rasterizer.  cam_pos / yaw / pitch / fovy /
+ * pix_aspect are uCamPos, uYaw, uPitch, uFovY (radians), uPixAspect.  Outputs (each may be NULL, row 0 = top):
+ * rgba cols*rows*4 (alpha 255), ascii cols*rows codes; ar_set_ascii and ar_set_strip apply as for ar_render.
+ * Without a scene the call succeeds and leaves the outputs untouched (raytrace.js:321). */
+int ar_rt_render(ar_ctx *ctx, int cols, int rows, const float cam_pos[3], float yaw, float pitch, float fovy,
+                 float pix_aspect, uint8_t *rgba, uint8_t *ascii);
+
+/* The same frame without the copies: enqueue, then ar_sync / ar_read / ar_device_buffer as after
+ * ar_render_async (the depth plane is not written by ray frames). */
+int ar_rt_render_async(ar_ctx *ctx, int cols, int rows, const float cam_pos[3], float yaw, float pitch, float fovy,
+                       float pix_aspect);
+
 /* Per-kernel timing with HIP events on the context's stream.  While on, every launch is bracketed by
  * events; ar_kernel_stats drains them (blocking) and reports, per kernel slot, the number of launches
  * and the summed duration in milliseconds since the last call.  names receives static strings. */
-#define AR_N_KERNELS 12
+#define AR_N_KERNELS 13
 int ar_set_profiling(ar_ctx *ctx, int on);
 int ar_kernel_stats(ar_ctx *ctx, const char *names[AR_N_KERNELS], uint32_t launches[AR_N_KERNELS], float total_ms[AR_N_KERNELS]);
 

@@ -507,3 +507,233 @@ int orc_present(const uint8_t *rgba, const uint8_t *codes, int cols, int rows, c
             }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Ray backend: the reference's deterministic single-bounce ray tracer
+ * (js/render/backends/raytrace_shader.js:62-242; uniforms as js/render/backends/raytrace.js:195-389
+ * uploads them).  PARITY UNPINNED: the arithmetic is GLSL inside the browser's WebGL implementation and
+ * the reference holds no output of it, so this restatement is the definition.  Choices GLSL leaves open:
+ *   - binary32 throughout, no fused multiply-add, correctly rounded / and sqrt, expressions left to right;
+ *     dot(a,b) = (a.x*b.x + a.y*b.y) + a.z*b.z; cross by components; length = sqrt(dot);
+ *     normalize(v) = v * (1/sqrt(dot(v,v))), and the zero vector for dot == 0; inversesqrt(x) = 1/sqrt(x);
+ *     reflect(I,N) = I - (2*dot(N,I))*N; clamp(x,a,b) = min(max(x,a),b); max/min are fmaxf/fminf.
+ *   - the per-frame camera terms (cos/sin of yaw and pitch, tan(fovy/2)) are uniform over the frame; they
+ *     are evaluated once on the host in binary64 from the binary32 uniform values and rounded to binary32.
+ *   - a fragment sits at (i + 0.5, j + 0.5) in GL window coordinates; output row 0 is the top image row
+ *     (flipAndCopy after readPixels, raytrace.js:398-402); colour byte = floor(clamp(c,0,1)*255 + 0.5),
+ *     alpha 255.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int n_spheres; const float *spheres4; const int32_t *sphere_mat;
+    int n_planes;  const float *planes4;  const int32_t *plane_mat;
+    int n_tris;    const float *tri_a, *tri_b, *tri_c; const int32_t *tri_mat;
+    int n_mats;    const float *mat_albedo; const int32_t *mat_reflective;
+    int n_pl;      const float *pl_pos, *pl_col;
+    int n_dl;      const float *dl_dir, *dl_col;
+    float env[3];
+} orc_rt_scene;
+
+#define RT_EPS 1e-4f
+#define RT_FAR 1e6f
+
+typedef struct { float x, y, z; } v3;
+static v3 v3_(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static v3 vsub(v3 a, v3 b) { return v3_(a.x - b.x, a.y - b.y, a.z - b.z); }
+static v3 vadd(v3 a, v3 b) { return v3_(a.x + b.x, a.y + b.y, a.z + b.z); }
+static v3 vscale(v3 a, float s) { return v3_(a.x * s, a.y * s, a.z * s); }
+static float vdot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static v3 vcross(v3 a, v3 b) { return v3_(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+static v3 vnorm(v3 a) { const float d = vdot(a, a); return d > 0.0f ? vscale(a, 1.0f / sqrtf(d)) : v3_(0.0f, 0.0f, 0.0f); }
+static v3 vload(const float *p) { return v3_(p[0], p[1], p[2]); }
+
+static float rt_sphere(v3 ro, v3 rd, const float *s)            /* raytrace_shader.js:89-101 */
+{
+    const v3 oc = vsub(ro, vload(s));
+    const float b = vdot(oc, rd);
+    const float c = vdot(oc, oc) - s[3] * s[3];
+    const float h = b * b - c;
+    if (h < 0.0f) return -1.0f;
+    const float q = sqrtf(h);
+    const float t1 = -b - q, t2 = -b + q;
+    if (t1 > RT_EPS) return t1;
+    if (t2 > RT_EPS) return t2;
+    return -1.0f;
+}
+
+static float rt_plane(v3 ro, v3 rd, const float *pl)             /* :104-109 */
+{
+    const v3 n = vload(pl);
+    const float denom = vdot(n, rd);
+    if (fabsf(denom) < 1e-6f) return -1.0f;
+    const float t = (-pl[3] - vdot(n, ro)) / denom;
+    return t > RT_EPS ? t : -1.0f;
+}
+
+static float rt_tri(v3 ro, v3 rd, v3 a, v3 b, v3 c, v3 *n)       /* :111-125 */
+{
+    const v3 e1 = vsub(b, a), e2 = vsub(c, a);
+    const v3 p = vcross(rd, e2);
+    const float det = vdot(e1, p);
+    *n = v3_(0.0f, 0.0f, 0.0f);
+    if (fabsf(det) < 1e-6f) return -1.0f;
+    const float inv = 1.0f / det;
+    const v3 t = vsub(ro, a);
+    const float u = vdot(t, p) * inv;
+    if (u < 0.0f || u > 1.0f) return -1.0f;
+    const v3 q = vcross(t, e1);
+    const float v = vdot(rd, q) * inv;
+    if (v < 0.0f || u + v > 1.0f) return -1.0f;
+    const float tt = vdot(e2, q) * inv;
+    if (tt <= RT_EPS) return -1.0f;
+    *n = vnorm(vcross(e1, e2));
+    if (vdot(*n, rd) > 0.0f) *n = v3_(-n->x, -n->y, -n->z);
+    return tt;
+}
+
+typedef struct { float t; int m; v3 n; } rt_hit;
+
+static rt_hit rt_intersect(const orc_rt_scene *S, v3 ro, v3 rd)  /* :129-150 */
+{
+    rt_hit H = { RT_FAR, -1, { 0.0f, 0.0f, 0.0f } };
+    for (int i = 0; i < S->n_spheres; i++) {
+        const float *s = S->spheres4 + 4 * i;
+        const float t = rt_sphere(ro, rd, s);
+        if (t > RT_EPS && t < H.t) {
+            H.t = t; H.m = S->sphere_mat[i];
+            const v3 pos = vadd(ro, vscale(rd, t));
+            const float r = fmaxf(s[3], 1e-6f);
+            const v3 d = vsub(pos, vload(s));
+            H.n = v3_(d.x / r, d.y / r, d.z / r);
+        }
+    }
+    for (int i = 0; i < S->n_planes; i++) {
+        const float t = rt_plane(ro, rd, S->planes4 + 4 * i);
+        if (t > RT_EPS && t < H.t) { H.t = t; H.m = S->plane_mat[i]; H.n = vload(S->planes4 + 4 * i); }
+    }
+    for (int i = 0; i < S->n_tris; i++) {
+        v3 n;
+        const float t = rt_tri(ro, rd, vload(S->tri_a + 3 * i), vload(S->tri_b + 3 * i), vload(S->tri_c + 3 * i), &n);
+        if (t > RT_EPS && t < H.t) { H.t = t; H.m = S->tri_mat[i]; H.n = n; }
+    }
+    return H;
+}
+
+static int rt_occluded(const orc_rt_scene *S, v3 ro, v3 rd, float max_t)   /* :152-166: spheres and triangles only */
+{
+    for (int i = 0; i < S->n_spheres; i++) {
+        const float t = rt_sphere(ro, rd, S->spheres4 + 4 * i);
+        if (t > RT_EPS && t < max_t) return 1;
+    }
+    for (int i = 0; i < S->n_tris; i++) {
+        v3 n;
+        const float t = rt_tri(ro, rd, vload(S->tri_a + 3 * i), vload(S->tri_b + 3 * i), vload(S->tri_c + 3 * i), &n);
+        if (t > RT_EPS && t < max_t) return 1;
+    }
+    return 0;
+}
+
+static v3 rt_shade_diffuse(const orc_rt_scene *S, v3 pos, v3 N, v3 albedo)   /* :168-196 */
+{
+    const float z = fmaxf(N.y * 0.0f, 0.0f);
+    v3 Lo = v3_(S->env[0] * z, S->env[1] * z, S->env[2] * z);
+    const v3 org = vadd(pos, vscale(N, RT_EPS));
+    for (int i = 0; i < S->n_dl; i++) {
+        const v3 d = vload(S->dl_dir + 3 * i);
+        const v3 L = vnorm(v3_(-d.x, -d.y, -d.z));
+        const float ndl = fmaxf(vdot(N, L), 0.0f);
+        if (ndl > 0.0f && !rt_occluded(S, org, L, 1e5f)) {
+            const float *c = S->dl_col + 3 * i;
+            Lo = v3_(Lo.x + (albedo.x * c[0]) * ndl, Lo.y + (albedo.y * c[1]) * ndl, Lo.z + (albedo.z * c[2]) * ndl);
+        }
+    }
+    for (int i = 0; i < S->n_pl; i++) {
+        const v3 Lv = vsub(vload(S->pl_pos + 3 * i), pos);
+        const float dist2 = fmaxf(vdot(Lv, Lv), 1e-6f);
+        const v3 L = vscale(Lv, 1.0f / sqrtf(dist2));
+        const float ndl = fmaxf(vdot(N, L), 0.0f);
+        if (ndl > 0.0f && !rt_occluded(S, org, L, sqrtf(dist2) - 2.0f * RT_EPS)) {
+            const float att = 1.0f / (1.0f + dist2 * 0.05f);
+            const float w = ndl * att;
+            const float *c = S->pl_col + 3 * i;
+            Lo = v3_(Lo.x + (albedo.x * c[0]) * w, Lo.y + (albedo.y * c[1]) * w, Lo.z + (albedo.z * c[2]) * w);
+        }
+    }
+    return Lo;
+}
+
+static void rt_material(const orc_rt_scene *S, int m, v3 *albedo, int *reflective)   /* :71-86,218-220 */
+{
+    const int mi = (int)fminf(fmaxf((float)m, 0.0f), (float)(S->n_mats - 1));
+    *albedo = v3_(0.8f, 0.8f, 0.8f);
+    *reflective = 0;
+    if (mi >= 0 && mi < S->n_mats) { *albedo = vload(S->mat_albedo + 3 * mi); *reflective = S->mat_reflective[mi] != 0; }
+}
+
+/* Camera terms of raytrace_shader.js:66-70,203-207, evaluated once per frame: basis[0..2] = uu, [3..5] = vv,
+ * [6..8] = ww, [9] = focal. */
+void orc_rt_camera(float yaw, float pitch, float fovy, float *basis)
+{
+    const double cp = cos((double)pitch), sp = sin((double)pitch), cy = cos((double)yaw), sy = sin((double)yaw);
+    const v3 ww = vnorm(v3_((float)(cp * cy), (float)sp, (float)(cp * sy)));
+    v3 uu = vnorm(vcross(ww, v3_(0.0f, 1.0f, 0.0f)));
+    if (sqrtf(vdot(uu, uu)) < 1e-3f) uu = v3_(1.0f, 0.0f, 0.0f);
+    const v3 vv = vnorm(vcross(uu, ww));
+    basis[0] = uu.x; basis[1] = uu.y; basis[2] = uu.z;
+    basis[3] = vv.x; basis[4] = vv.y; basis[5] = vv.z;
+    basis[6] = ww.x; basis[7] = ww.y; basis[8] = ww.z;
+    basis[9] = 1.0f / fmaxf(1e-6f, (float)tan(0.5 * (double)fovy));
+}
+
+/* One frame of the ray backend; rgba_out cols*rows*4, row 0 = top.  Returns 0, or -1 on bad arguments. */
+int orc_rt_render(const orc_rt_scene *S, int cols, int rows, const float *cam_pos, float yaw, float pitch, float fovy,
+                  float pix_aspect, uint8_t *rgba_out)
+{
+    if (!S || cols <= 0 || rows <= 0 || !cam_pos || !rgba_out) return -1;
+    float B[10];
+    orc_rt_camera(yaw, pitch, fovy, B);
+    const v3 uu = vload(B), vv = vload(B + 3), ww = vload(B + 6);
+    const float focal = B[9];
+    const float aspect = ((float)cols / (float)rows) * fmaxf(pix_aspect, 1e-6f);
+    const v3 ro = vload(cam_pos);
+    for (int j = 0; j < rows; j++) {
+        for (int i = 0; i < cols; i++) {
+            float px = -1.0f + 2.0f * (((float)i + 0.5f) / (float)cols);
+            const float py = -1.0f + 2.0f * (((float)j + 0.5f) / (float)rows);
+            px = px * aspect;
+            const v3 rd = vnorm(v3_((px * uu.x + py * vv.x) + focal * ww.x, (px * uu.y + py * vv.y) + focal * ww.y,
+                                    (px * uu.z + py * vv.z) + focal * ww.z));
+            v3 col;
+            const rt_hit H = rt_intersect(S, ro, rd);
+            if (H.m < 0) {
+                col = vload(S->env);
+            } else {
+                const v3 hit = vadd(ro, vscale(rd, H.t));
+                const v3 N = vnorm(H.n);
+                v3 albedo; int refl;
+                rt_material(S, H.m, &albedo, &refl);
+                if (!refl) {
+                    col = rt_shade_diffuse(S, hit, N, albedo);
+                } else {
+                    const float d2 = 2.0f * vdot(N, rd);
+                    const v3 rdir = vsub(rd, vscale(N, d2));
+                    const v3 org = vadd(hit, vscale(N, RT_EPS));
+                    const rt_hit H2 = rt_intersect(S, org, rdir);
+                    if (H2.m < 0) {
+                        col = vload(S->env);
+                    } else {
+                        const v3 hit2 = vadd(org, vscale(rdir, H2.t));
+                        const v3 N2 = vnorm(H2.n);
+                        v3 alb2; int r2;
+                        rt_material(S, H2.m, &alb2, &r2);
+                        col = rt_shade_diffuse(S, hit2, N2, alb2);
+                    }
+                }
+            }
+            uint8_t *o = rgba_out + ((size_t)(rows - 1 - j) * cols + i) * 4;
+            const float c3[3] = { col.x, col.y, col.z };
+            for (int k = 0; k < 3; k++) o[k] = (uint8_t)(int)floorf(fminf(fmaxf(c3[k], 0.0f), 1.0f) * 255.0f + 0.5f);
+            o[3] = 255;
+        }
+    }
+    return 0;
+}

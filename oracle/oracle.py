@@ -150,3 +150,55 @@ def present(rgba, codes, cols, rows, atlas, cell_w, cell_h, gamma=1.0, grayscale
     if rc != 0:
         raise ValueError("orc_present rejected its arguments")
     return out
+
+
+class _RtScene(ctypes.Structure):
+    _f, _i = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)
+    _fields_ = [("n_spheres", ctypes.c_int), ("spheres4", _f), ("sphere_mat", _i),
+                ("n_planes", ctypes.c_int), ("planes4", _f), ("plane_mat", _i),
+                ("n_tris", ctypes.c_int), ("tri_a", _f), ("tri_b", _f), ("tri_c", _f), ("tri_mat", _i),
+                ("n_mats", ctypes.c_int), ("mat_albedo", _f), ("mat_reflective", _i),
+                ("n_pl", ctypes.c_int), ("pl_pos", _f), ("pl_col", _f),
+                ("n_dl", ctypes.c_int), ("dl_dir", _f), ("dl_col", _f),
+                ("env", ctypes.c_float * 3)]
+
+
+def rt_render(u, cols, rows, cam_pos, yaw, pitch, fovy, pix_aspect=1.0):
+    """Ray backend frame from the uniform arrays of the reference's RaytraceBackend (dict keyed by uniform
+    name: uNumS, uSpheres, uSm, ... uEnv; absent arrays are empty) -> rgba uint8 [rows, cols, 4], top-down."""
+    L = lib()
+    fpt, ipt = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)
+    keep, sc = [], _RtScene()
+
+    def arr(key, dtype, ptr):
+        a = np.ascontiguousarray(u.get(key, np.zeros(0)), dtype=dtype).reshape(-1)
+        keep.append(a)
+        return a.ctypes.data_as(ptr) if a.size else None
+
+    sc.n_spheres, sc.spheres4, sc.sphere_mat = int(u.get("uNumS", 0)), arr("uSpheres", np.float32, fpt), arr("uSm", np.int32, ipt)
+    sc.n_planes, sc.planes4, sc.plane_mat = int(u.get("uNumP", 0)), arr("uPlanes", np.float32, fpt), arr("uPm", np.int32, ipt)
+    sc.n_tris, sc.tri_a, sc.tri_b, sc.tri_c = int(u.get("uNumT", 0)), arr("uTa", np.float32, fpt), arr("uTb", np.float32, fpt), arr("uTc", np.float32, fpt)
+    sc.tri_mat = arr("uTm", np.int32, ipt)
+    sc.n_mats, sc.mat_albedo, sc.mat_reflective = int(u.get("uNumMats", 0)), arr("uMatAlbedo", np.float32, fpt), arr("uMatReflective", np.int32, ipt)
+    sc.n_pl, sc.pl_pos, sc.pl_col = int(u.get("uNumPL", 0)), arr("uPLPos", np.float32, fpt), arr("uPLCol", np.float32, fpt)
+    sc.n_dl, sc.dl_dir, sc.dl_col = int(u.get("uNumDL", 0)), arr("uDLDir", np.float32, fpt), arr("uDLCol", np.float32, fpt)
+    env = np.asarray(u.get("uEnv", (0, 0, 0)), dtype=np.float32).reshape(-1)
+    sc.env = (ctypes.c_float * 3)(*[float(x) for x in env[:3]])
+    L.orc_rt_render.argtypes = [ctypes.POINTER(_RtScene), ctypes.c_int, ctypes.c_int, fpt, ctypes.c_float, ctypes.c_float,
+                                ctypes.c_float, ctypes.c_float, ctypes.POINTER(ctypes.c_uint8)]
+    L.orc_rt_render.restype = ctypes.c_int
+    cam, camp = _f(cam_pos)
+    rgba = np.zeros((rows, cols, 4), dtype=np.uint8)
+    if L.orc_rt_render(ctypes.byref(sc), cols, rows, camp, yaw, pitch, fovy, pix_aspect, rgba.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))) != 0:
+        raise ValueError("orc_rt_render rejected its arguments")
+    return rgba
+
+
+def rt_camera(yaw, pitch, fovy):
+    """(uu, vv, ww, focal) of the ray backend's camera."""
+    L = lib()
+    L.orc_rt_camera.argtypes = [ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.POINTER(ctypes.c_float)]
+    L.orc_rt_camera.restype = None
+    b = np.zeros(10, dtype=np.float32)
+    L.orc_rt_camera(yaw, pitch, fovy, b.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return b[0:3], b[3:6], b[6:9], float(b[9])
