@@ -289,6 +289,89 @@ napi_value js_render(napi_env env, napi_callback_info info) {
     return out;
 }
 
+// rtSetScene(handle, {numS, S4, Si, numP, P4, Pi, numT, Ta, Tb, Tc, Ti, numMats, Ma, Mr, numPL, Ppos, Pcol, numDL, Ddir, Dcol, envCol}):
+// the packed uniform arrays of the ray backend (field names as RaytraceBackend._cache, raytrace.js:303-311)
+napi_value js_rt_set_scene(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    ar_rt_scene sc;
+    memset(&sc, 0, sizeof sc);
+    bool ok = true;
+    auto count = [&](const char *name) {
+        napi_value v;
+        int32_t x = 0;
+        if (napi_get_named_property(env, argv[1], name, &v) != napi_ok || napi_get_value_int32(env, v, &x) != napi_ok) ok = false;
+        return int(x);
+    };
+    auto array = [&](const char *name, napi_typedarray_type type, size_t need) -> const void * {
+        napi_value v;
+        void *data = nullptr;
+        size_t len = 0;
+        if (!ok || napi_get_named_property(env, argv[1], name, &v) != napi_ok) { ok = false; return nullptr; }
+        if (!get_typed(env, v, type, &data, &len, need == 0)) { ok = false; return nullptr; }
+        if (len < need) { ok = false; napi_throw_range_error(env, nullptr, "rtSetScene: array shorter than its count"); return nullptr; }
+        return need ? data : nullptr;
+    };
+    sc.n_spheres = count("numS"); sc.n_planes = count("numP"); sc.n_tris = count("numT");
+    sc.n_mats = count("numMats"); sc.n_pl = count("numPL"); sc.n_dl = count("numDL");
+    if (!ok || sc.n_spheres < 0 || sc.n_planes < 0 || sc.n_tris < 0 || sc.n_mats < 0 || sc.n_pl < 0 || sc.n_dl < 0) {
+        napi_throw_type_error(env, nullptr, "rtSetScene: counts missing or negative");
+        return nullptr;
+    }
+    sc.spheres4 = static_cast<const float *>(array("S4", napi_float32_array, size_t(sc.n_spheres) * 4));
+    sc.sphere_mat = static_cast<const int32_t *>(array("Si", napi_int32_array, size_t(sc.n_spheres)));
+    sc.planes4 = static_cast<const float *>(array("P4", napi_float32_array, size_t(sc.n_planes) * 4));
+    sc.plane_mat = static_cast<const int32_t *>(array("Pi", napi_int32_array, size_t(sc.n_planes)));
+    sc.tri_a = static_cast<const float *>(array("Ta", napi_float32_array, size_t(sc.n_tris) * 3));
+    sc.tri_b = static_cast<const float *>(array("Tb", napi_float32_array, size_t(sc.n_tris) * 3));
+    sc.tri_c = static_cast<const float *>(array("Tc", napi_float32_array, size_t(sc.n_tris) * 3));
+    sc.tri_mat = static_cast<const int32_t *>(array("Ti", napi_int32_array, size_t(sc.n_tris)));
+    sc.mat_albedo = static_cast<const float *>(array("Ma", napi_float32_array, size_t(sc.n_mats) * 3));
+    sc.mat_reflective = static_cast<const int32_t *>(array("Mr", napi_int32_array, size_t(sc.n_mats)));
+    sc.pl_pos = static_cast<const float *>(array("Ppos", napi_float32_array, size_t(sc.n_pl) * 3));
+    sc.pl_col = static_cast<const float *>(array("Pcol", napi_float32_array, size_t(sc.n_pl) * 3));
+    sc.dl_dir = static_cast<const float *>(array("Ddir", napi_float32_array, size_t(sc.n_dl) * 3));
+    sc.dl_col = static_cast<const float *>(array("Dcol", napi_float32_array, size_t(sc.n_dl) * 3));
+    const float *env3 = static_cast<const float *>(array("envCol", napi_float32_array, 3));
+    if (!ok || !env3) {
+        bool pending = false;
+        napi_is_exception_pending(env, &pending);
+        if (!pending) napi_throw_type_error(env, nullptr, "rtSetScene: scene arrays missing or of the wrong type");
+        return nullptr;
+    }
+    for (int k = 0; k < 3; k++) sc.env[k] = env3[k];
+    if (ar_rt_set_scene(ctx, &sc)) return throw_ar(env, ctx, "ar_rt_set_scene");
+    return nullptr;
+}
+
+// rtRender(handle, cols, rows, Float32Array camPos(3), yaw, pitch, fovY, pixAspect, rgba|null, ascii|null) -> true when a scene was drawn
+napi_value js_rt_render(napi_env env, napi_callback_info info) {
+    napi_value argv[10];
+    if (!get_args(env, info, 10, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    const int cols = get_i32(env, argv[1]), rows = get_i32(env, argv[2]);
+    void *cam, *rgba, *ascii;
+    size_t nc, nr, na;
+    if (!get_typed(env, argv[3], napi_float32_array, &cam, &nc, false) || !get_typed(env, argv[8], napi_uint8_array, &rgba, &nr, true) ||
+        !get_typed(env, argv[9], napi_uint8_array, &ascii, &na, true))
+        return nullptr;
+    double f[4];
+    for (int k = 0; k < 4; k++)
+        if (napi_get_value_double(env, argv[4 + k], &f[k]) != napi_ok) { napi_throw_type_error(env, nullptr, "rtRender: numbers expected"); return nullptr; }
+    const size_t n = size_t(cols > 0 ? cols : 0) * size_t(rows > 0 ? rows : 0);
+    if (nc != 3 || (rgba && nr != n * 4) || (ascii && na != n)) {
+        napi_throw_range_error(env, nullptr, "rtRender: array size does not match (camera 3, rgba cols*rows*4, ascii cols*rows)");
+        return nullptr;
+    }
+    if (ar_rt_render(ctx, cols, rows, static_cast<const float *>(cam), float(f[0]), float(f[1]), float(f[2]), float(f[3]),
+                     static_cast<uint8_t *>(rgba), static_cast<uint8_t *>(ascii)))
+        return throw_ar(env, ctx, "ar_rt_render");
+    return nullptr;
+}
+
 napi_value js_quantize(napi_env env, napi_callback_info info) {
     napi_value argv[5];
     if (!get_args(env, info, 5, argv)) return nullptr;
@@ -409,6 +492,8 @@ napi_value init(napi_env env, napi_value exports) {
         {"setStrip", nullptr, js_set_strip, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setOption", nullptr, js_set_option, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"render", nullptr, js_render, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"rtSetScene", nullptr, js_rt_set_scene, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"rtRender", nullptr, js_rt_render, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"quantize", nullptr, js_quantize, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"frameCounters", nullptr, js_frame_counters, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"allocHost", nullptr, js_alloc_host, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

@@ -6,16 +6,20 @@
 //       (errors swallowed), calls factory() with no arguments and replays the last scene
 //   setScene(scene) / renderScene(timeSec, framebuffer, appState) / renderRaw(args) /
 //   getPixels(args) / disposeGPU()
-// Differences: the built-in registry holds the HIP raster backend ('hip'); 'raster' and the
-// reference's aliases for it resolve to 'hip'; the default backend is 'hip'.
+// Differences: the built-in registry holds the HIP raster backend ('hip') and the HIP ray backend ('raytrace',
+// aliases 'rt' and 'ray' as in the reference); 'raster' and the reference's aliases for it resolve to 'hip';
+// the default backend is 'hip'; there is no path tracer.
 import { HipRasterBackend } from './hip_backend.js';
+import { HipRaytraceBackend } from './hip_raytrace_backend.js';
 
 const _registry = new Map([
   ['hip', () => new HipRasterBackend()],
+  ['raytrace', () => new HipRaytraceBackend()],
 ]);
 
 const _alias = new Map([
   ['raster', 'hip'], ['r', 'hip'], ['rasterizer', 'hip'], ['gpu', 'hip'],
+  ['rt', 'raytrace'], ['ray', 'raytrace'],
 ]);
 
 let _active = null;

@@ -24,6 +24,9 @@
  *   triangles (optional)                    pathtrace_shader.js:125-152,256-258        reference applies it in
  *                                                                                      its path tracer only)
  *
+ *   ray backend (orc_rt_render)             js/render/backends/raytrace_shader.js      (GLSL; unpinned; its
+ *                                           :62-242                                    uniforms are pinned)
+ *
  * PARITY UNPINNED for the rows marked "WebGL"/"GLSL": that arithmetic runs inside the browser's WebGL
  * implementation, which is not part of the reference tree and has no golden outputs there.  For those
  * rows this file is the definition: it follows the OpenGL ES rules the reference's GL state selects

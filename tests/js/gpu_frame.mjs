@@ -125,6 +125,28 @@ const dump = (name, ta) => fs.writeFileSync(path.join(outDir, name), Buffer.from
     tb.dispose();
   }
 
+  // the ray backend under the reference's names: router -> HipRaytraceBackend -> ar_rt_set_scene / ar_rt_render
+  {
+    const rtRef = JSON.parse(fs.readFileSync(path.join(here, '..', 'golden', 'ref_raytrace_uniforms.json'), 'utf8'));
+    const c = rtRef.cases.find((x) => x.scene === 'unified' && x.cam_name === 'orbit');
+    const savedAspect = config.PATH_TRACER.PIXEL_ASPECT;
+    if (c.pixelAspect === null) delete config.PATH_TRACER.PIXEL_ASPECT; else config.PATH_TRACER.PIXEL_ASPECT = c.pixelAspect;
+    if (router.setBackend('rt') !== 'raytrace') throw new Error('alias rt should resolve to raytrace');
+    router.setScene(rtRef.scenes.unified);
+    setCamera(c.camera.pos, c.camera.yaw, c.camera.pitch);
+    const fb = new Uint8ClampedArray(c.cols * c.rows * 4), state = { cols: c.cols, rows: c.rows, ascii: new Uint8Array(c.cols * c.rows) };
+    if (router.renderScene(0.0, fb, state) !== undefined) throw new Error('render must return undefined');
+    dump('rt.rgba', fb); dump('rt.ascii', state.ascii);
+    const raw = router.getPixels({});
+    if (raw[0] !== fb[((c.rows - 1) * c.cols) * 4]) throw new Error('raw getPixels of the ray backend should be bottom-up');
+    const tiny = new Uint8ClampedArray(8).fill(3);
+    router.renderScene(0.0, tiny, state);
+    if (!tiny.every((v) => v === 3)) throw new Error('mismatched framebuffer must stay untouched');
+    meta.raytrace = { scene: 'unified', cam_name: 'orbit', cols: c.cols, rows: c.rows };
+    config.PATH_TRACER.PIXEL_ASPECT = savedAspect;
+    router.setBackend('raster');
+  }
+
   // empty scene: early return, buffers untouched (raster.js:274)
   router.setScene({});
   const untouched = new Uint8ClampedArray(80 * 40 * 4).fill(9);

@@ -90,6 +90,32 @@ const sha = (ta) => crypto.createHash('sha256').update(Buffer.from(ta.buffer, ta
     results.textured[c.name] = { uv8: sha(g.uv8), idx: sha(g.idx), verts: g.vbo.length / 9 };
   }
 
+  /* ---- ray backend host half vs the uniforms recorded from the reference's RaytraceBackend ---- */
+  const rt = await import(path.join(JS, 'hip_raytrace_backend.js'));
+  const rtRef = JSON.parse(fs.readFileSync(path.join(goldenDir, 'ref_raytrace_uniforms.json'), 'utf8'));
+  const i32 = (b64) => { const b = Buffer.from(b64 || '', 'base64'); return new Int32Array(b.buffer.slice(b.byteOffset, b.byteOffset + b.length)); };
+  assert.deepStrictEqual(rt.raytraceLimits(), rtRef.cases[0].limits); results.checks++;
+  for (const c of rtRef.cases) {
+    const P = rt.packRaytraceScene(rtRef.scenes[c.scene], c.limits), U = c.uniforms, tag = ' (' + c.scene + ')';
+    const counts = { uNumS: P.numS, uNumP: P.numP, uNumT: P.numT, uNumMats: P.numMats, uNumPL: P.numPL, uNumDL: P.numDL };
+    for (const [k, v] of Object.entries(counts)) ok(U[k] === v, k + tag);
+    const arrays = [['uSpheres[0]', P.S4, P.numS, f32], ['uSm[0]', P.Si, P.numS, i32], ['uPlanes[0]', P.P4, P.numP, f32], ['uPm[0]', P.Pi, P.numP, i32],
+      ['uTa[0]', P.Ta, P.numT, f32], ['uTb[0]', P.Tb, P.numT, f32], ['uTc[0]', P.Tc, P.numT, f32], ['uTm[0]', P.Ti, P.numT, i32],
+      ['uMatAlbedo[0]', P.Ma, P.numMats, f32], ['uMatReflective[0]', P.Mr, P.numMats, i32],
+      ['uPLPos[0]', P.Ppos, P.numPL, f32], ['uPLCol[0]', P.Pcol, P.numPL, f32], ['uDLDir[0]', P.Ddir, P.numDL, f32], ['uDLCol[0]', P.Dcol, P.numDL, f32]];
+    for (const [name, got, n, dec] of arrays) {
+      if (n > 0) ok(bytesEqual(got, dec(U[name])), name + tag);       // the reference uploads an array only when its count is positive
+      else ok(U[name] === undefined, name + ' must not be uploaded' + tag);
+    }
+    ok(bytesEqual(P.envCol, f32(U.uEnv)), 'uEnv' + tag);
+    if (c.pixelAspect === null) delete config.PATH_TRACER.PIXEL_ASPECT; else config.PATH_TRACER.PIXEL_ASPECT = c.pixelAspect;
+    setCamera(c.camera.pos, c.camera.yaw, c.camera.pitch);
+    const F = rt.raytraceFrameUniforms();
+    ok(bytesEqual(F.camPos, f32(U.uCamPos)) && Math.fround(F.yaw) === f32(U.uYaw)[0] && Math.fround(F.pitch) === f32(U.uPitch)[0] &&
+      Math.fround(F.fovY) === f32(U.uFovY)[0] && Math.fround(F.pixAspect) === f32(U.uPixAspect)[0], 'frame uniforms' + tag);
+  }
+  delete config.PATH_TRACER.PIXEL_ASPECT;
+
   /* ---- router semantics (js/gpu_renderer.js:52-111 of the reference) ---- */
   assert.throws(() => router.registerBackend('', () => ({})), /registerBackend\(name, factory\): invalid args/);
   assert.throws(() => router.registerBackend('x', 42), /invalid args/);
@@ -99,6 +125,7 @@ const sha = (ta) => crypto.createHash('sha256').update(Buffer.from(ta.buffer, ta
   router.registerBackend('FakeA', mk('a'));
   router.registerBackend('fakeb', mk('b'));
   ok(router.listBackends().includes('fakea') && router.listBackends().includes('hip'), 'names are lower-cased');
+  ok(router.listBackends().includes('raytrace'), 'the ray backend is registered under the reference name');
   ok(router.setBackend('FAKEA') === 'fakea' && router.getBackend() === 'fakea', 'setBackend returns the canonical name');
   router.setScene({ tag: 's1' });
   router.renderScene(0, null, { cols: 7, rows: 3 });

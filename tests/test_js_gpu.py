@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_node_harness_frames_match_oracle(pkg, oracle, tmp_path):
+def test_node_harness_frames_match_oracle(pkg, oracle, tmp_path, rt_uniforms_of):
     node = shutil.which("node")
     assert node, "node is required for the JavaScript host"
     r = subprocess.run([node, os.path.join(ROOT, "tests", "js", "gpu_frame.mjs"), str(tmp_path)],
@@ -86,3 +86,14 @@ def test_node_harness_frames_match_oracle(pkg, oracle, tmp_path):
     got_plain = np.fromfile(tmp_path / "poster_plain.rgba", dtype=np.uint8).reshape(rows, cols, 4)
     # (sphere vertices come from libm sin/cos, which V8 and glibc may round differently in the last place)
     assert np.mean(got_plain == plain) > 0.999 and np.all(got_plain[..., 3] == 255)
+
+    # the ray backend through the router: same image as the oracle fed with the reference's recorded uniforms
+    rtm = meta["raytrace"]
+    with open(os.path.join(ROOT, "tests", "golden", "ref_raytrace_uniforms.json")) as fh:
+        rcase = next(c for c in json.load(fh)["cases"] if c["scene"] == rtm["scene"] and c["cam_name"] == rtm["cam_name"])
+    u, cam = rt_uniforms_of(rcase)
+    cols, rows = rtm["cols"], rtm["rows"]
+    want = oracle.rt_render(u, cols, rows, cam["pos"], cam["yaw"], cam["pitch"], cam["fovy"], cam["pix_aspect"])
+    got = np.fromfile(tmp_path / "rt.rgba", dtype=np.uint8).reshape(rows, cols, 4)
+    assert np.array_equal(got, want) and len(np.unique(want.reshape(-1, 4), axis=0)) > 50
+    assert np.array_equal(np.fromfile(tmp_path / "rt.ascii", dtype=np.uint8).reshape(rows, cols), oracle.quantize(want, cols, rows, ramp, 1, 2, 12))
