@@ -4,6 +4,7 @@ There is no CPU fallback: if the library is missing or no GPU is present, constr
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -50,6 +51,14 @@ def load_library():
         raise AsciiRastError(
             "HIP library not built: %s is missing (run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C ascii-renderer_amd/csrc`)" % LIB_PATH)
+    if "torch" not in sys.modules:
+        # PyTorch's wheel carries its own HIP runtime under another file name.  The loader shares it with this
+        # library only when PyTorch is loaded first; the other way round the process ends up with two runtimes
+        # and PyTorch then finds no device.  The harness uses both, so PyTorch (when installed) goes first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = ctypes.CDLL(LIB_PATH)
     vp = ctypes.c_void_p
     L.ar_create.argtypes = [ctypes.c_int]

@@ -49,29 +49,37 @@ class StripBatcher:
     takes less, so gathering frame by frame would leave the GPUs waiting for the host.  Frame k of the
     last gathered batch is frame(k) (every rank holds every full frame).
 
+    There are `rings` rings, used in rotation (two by default): while one is being gathered the frames of the
+    next batch already fill the other, so neither the renderer nor the interconnect waits for the other.
+
     `device` tensors live wherever the bands live (HBM with RCCL, host memory with gloo in the tests)."""
 
-    def __init__(self, band_rows, cols, batch, device, before_gather=None, after_gather=None):
-        """before_gather / after_gather: called around each all-gather, e.g. to make the gathering stream
-        wait for the frames that filled the ring and the next frames wait for the gather (stream-ordered)."""
+    def __init__(self, band_rows, cols, batch, device, before_gather=None, after_gather=None, rings=2):
+        """before_gather: called right before each all-gather, to make the gathering stream wait for the frames
+        that filled the ring.  after_gather: makes the frames enqueued from then on wait for the gathers
+        enqueued so far (stream-ordered, no host wait); with one ring it is called right after each gather, with
+        more it is called before the next gather is enqueued - the frames that follow reuse the ring of an
+        earlier gather, not of the one about to start."""
         self.before_gather, self.after_gather = before_gather, after_gather
         self.world = dist.get_world_size()
-        self.batch, self.h, self.cols = int(batch), int(band_rows), int(cols)
-        self.ring = torch.empty((self.batch, self.h, self.cols), dtype=torch.uint8, device=device)
-        self.out = torch.empty((self.world, self.batch, self.h, self.cols), dtype=torch.uint8, device=device)
+        self.batch, self.h, self.cols, self.rings = int(batch), int(band_rows), int(cols), max(1, int(rings))
+        self.ring = torch.empty((self.rings, self.batch, self.h, self.cols), dtype=torch.uint8, device=device)
+        self.out = torch.empty((self.rings, self.world, self.batch, self.h, self.cols), dtype=torch.uint8, device=device)
+        self.cur = 0           # ring being filled
+        self.last = 0          # ring of the last gathered batch
         self.filled = 0
-        self.gathered = 0      # frames held by `out`
+        self.gathered = 0      # frames held by out[last]
 
     def push(self, band):
         """Copies one frame's band into the ring (stream-ordered on the current stream); gathers when full."""
-        self.ring[self.filled].copy_(band)
+        self.ring[self.cur, self.filled].copy_(band)
         self.filled += 1
         if self.filled == self.batch:
             self.flush()
 
     def slot_ptr(self):
         """Device address of the ring slot the next frame's band belongs in (for ar_set_ascii_target)."""
-        return self.ring.data_ptr() + self.filled * self.h * self.cols
+        return self.ring.data_ptr() + (self.cur * self.batch + self.filled) * self.h * self.cols
 
     def advance(self):
         """The renderer has been told to write the band into slot_ptr() itself (no copy); gathers when full."""
@@ -82,15 +90,18 @@ class StripBatcher:
     def flush(self):
         if self.filled == 0:
             return
+        if self.after_gather and self.rings > 1:
+            self.after_gather()
         if self.before_gather:
             self.before_gather()
-        dist.all_gather_into_tensor(self.out.view(-1), self.ring.view(-1))
-        if self.after_gather:
+        dist.all_gather_into_tensor(self.out[self.cur].view(-1), self.ring[self.cur].view(-1))
+        if self.after_gather and self.rings == 1:
             self.after_gather()
-        self.gathered, self.filled = self.filled, 0
+        self.last, self.gathered, self.filled = self.cur, self.filled, 0
+        self.cur = (self.cur + 1) % self.rings
 
     def frame(self, k):
         """Full grid [world * band_rows, cols] of frame k of the last gathered batch."""
         if not 0 <= k < self.gathered:
             raise IndexError("frame %d of a batch of %d" % (k, self.gathered))
-        return self.out[:, k].reshape(self.world * self.h, self.cols)
+        return self.out[self.last][:, k].reshape(self.world * self.h, self.cols)

@@ -87,8 +87,9 @@ def main():
         R.set_strip(row0, row1)
         torch.cuda.set_stream(torch.cuda.Stream())         # a real stream handle (the default stream's is 0)
         ts = torch.cuda.current_stream().cuda_stream
-        # the gather waits (on its stream) for the frames that filled the ring, the frames after it wait for
-        # the gather before they write the ring again: two stream-ordered hand-overs per batch, no host waits
+        # two rings in rotation: the gather of one waits (on its stream) for the frames that filled it while the next
+        # frames already fill the other; frames wait for a gather only when they come back to its ring, by which
+        # time it is long over: two stream-ordered hand-overs per batch, no host waits, no pipeline drain
         batcher = mg.StripBatcher(row1 - row0, args.cols, max(1, args.gather_batch), "cuda",
                                   before_gather=lambda: R.stream_wait_frame(ts), after_gather=lambda: R.frame_wait_stream(ts))
     R.render_async(args.cols, args.rows)

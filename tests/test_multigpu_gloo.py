@@ -48,6 +48,21 @@ def _worker(rank, world, port, tmp):
     sb.push(torch.from_numpy(frames[2][row0:row1].copy()))
     sb.flush()
     ok = ok and sb.gathered == 1 and np.array_equal(sb.frame(0).numpy(), frames[2])
+    # ring rotation and the order of the hand-over callbacks: with two rings "frames wait for earlier gathers" comes
+    # before the gather of the batch just finished, with one ring after it; gathered frames stay readable while the
+    # other ring fills
+    for rings, want in ((2, ["release", "acquire"]), (1, ["acquire", "release"])):
+        log = []
+        sb = mg.StripBatcher(row1 - row0, cols, 1, "cpu", before_gather=lambda: log.append("acquire"),
+                             after_gather=lambda: log.append("release"), rings=rings)
+        for k in range(3):
+            ptr = sb.slot_ptr()
+            ok = ok and ptr == sb.ring.data_ptr() + (k % rings) * (row1 - row0) * cols
+            sb.ring[sb.cur, 0].copy_(torch.from_numpy(frames[k][row0:row1].copy()))
+            mark = len(log)
+            sb.advance()
+            ok = ok and log[mark:] == want
+            ok = ok and np.array_equal(sb.frame(0).numpy(), frames[k])
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
