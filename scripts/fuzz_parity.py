@@ -1,7 +1,9 @@
 """Randomised parity sweep: many small scenes with random geometry (soups of tiny to screen-filling
 triangles, duplicated and coplanar triangles, shared vertices with smooth normals, NaN / out-of-range
-input), cameras (also inside the geometry), grids, lights, ramps, smoothing parameters, strips and
-both resolve paths, each compared bit for bit with the oracle.   usage: fuzz_parity.py [cases] [seed]"""
+input), cameras (also inside the geometry), grids, lights, ramps, smoothing parameters, strips,
+both resolve paths, random atlas texturing (texel coordinates, sample bits, atlases of every alpha class and
+of degenerate sizes), meshes built on the GPU from indexed input, and ray-backend scenes, each compared bit
+for bit with the oracle.   usage: fuzz_parity.py [cases] [seed]"""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -50,9 +52,56 @@ def make_case(rng):
                                     "intensity": float(rng.uniform(0, 30))} for _ in range(npl)]}} if npl else {}
     ramp = str(rng.choice(["@%#*+=-:. ", " .:-=+*#%@", "ab", "x", "".join(chr(33 + k) for k in range(90))]))
     mode = (bool(rng.random() < 0.7), int(rng.integers(1, 4)), int(rng.integers(1, 30)))
-    return {"vbo": np.ascontiguousarray(vbo, dtype=np.float32), "idx": np.ascontiguousarray(idx, dtype=np.uint32), "proj": proj,
+    T = idx.size // 3
+    uv8 = atlas = None
+    if rng.random() < 0.35:
+        W, H = int(rng.choice([1, 2, 5, 32, 100])), int(rng.choice([1, 2, 7, 32]))
+        uv8 = np.zeros((T, 8), dtype=np.uint16)
+        uv8[:, :6] = rng.integers(0, max(W, H) + 3, size=(T, 6))
+        uv8[:, 6] = rng.integers(0, 2, size=T)
+        if rng.random() < 0.3:
+            uv8[rng.integers(0, T), :6] = 65535
+        atlas = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
+        atlas[..., 3] = rng.choice(np.array([0, 1, 1, 32, 90, 126, 2, 31, 127, 255], dtype=np.uint8), size=(H, W))
+    indexed = None
+    if kind <= 2 and rng.random() < 0.4:       # hand the soup over as an indexed list and let the GPU build the vertex buffer
+        indexed = (P, I, C)
+    return {"uv8": uv8, "atlas": atlas, "indexed": indexed,
+            "vbo": np.ascontiguousarray(vbo, dtype=np.float32), "idx": np.ascontiguousarray(idx, dtype=np.uint32), "proj": proj,
             "view": view, "lights": ar.host.pack_lights(scene), "cols": cols, "rows": rows, "ramp": ramp, "mode": mode,
             "path": int(rng.integers(0, 2)), "pool": int(rng.choice([0, 0, 0, 64, 5000])), "overlap": int(rng.integers(0, 3))}
+
+
+def rt_case(rng):
+    """Random ray-backend scene in the uniform layout, camera anywhere (also inside spheres)."""
+    n_s, n_p, n_t, n_m = int(rng.choice([0, 1, 5, 32, 60])), int(rng.choice([0, 1, 3])), int(rng.choice([0, 2, 20, 64, 150])), int(rng.choice([0, 1, 6, 64]))
+    sph = np.concatenate([rng.uniform(-6, 6, size=(n_s, 3)), rng.choice([0.0, 0.3, 1.0, 4.0], size=(n_s, 1))], axis=1)
+    tri = rng.uniform(-7, 7, size=(n_t, 1, 3)) + rng.uniform(-2, 2, size=(n_t, 3, 3)) * rng.choice([0.0, 0.3, 1.0, 6.0], size=(n_t, 1, 1))
+    pl = rng.uniform(-1, 1, size=(n_p, 4)); pl[:, 3] = rng.uniform(0, 9, size=n_p)
+    n_pl, n_dl = int(rng.integers(0, 9)), int(rng.integers(0, 3))
+    return {"uNumS": n_s, "uSpheres": sph, "uSm": rng.integers(-1, n_m + 2, size=n_s), "uNumP": n_p, "uPlanes": pl, "uPm": rng.integers(-1, n_m + 2, size=n_p),
+            "uNumT": n_t, "uTa": tri[:, 0], "uTb": tri[:, 1], "uTc": tri[:, 2], "uTm": rng.integers(-1, n_m + 2, size=n_t),
+            "uNumMats": n_m, "uMatAlbedo": rng.uniform(0, 1.2, size=(n_m, 3)), "uMatReflective": (rng.uniform(size=n_m) < 0.4).astype(np.int32),
+            "uNumPL": n_pl, "uPLPos": rng.uniform(-8, 8, size=(n_pl, 3)), "uPLCol": rng.uniform(0, 25, size=(n_pl, 3)),
+            "uNumDL": n_dl, "uDLDir": rng.uniform(-1, 1, size=(n_dl, 3)) * rng.choice([0.0, 1.0, 1.0]), "uDLCol": rng.uniform(0, 1.5, size=(n_dl, 3)),
+            "uEnv": rng.uniform(0, 1.3, size=3)}
+
+
+def rt_check(R, rng, n):
+    u = rt_case(rng)
+    cols, rows = int(rng.choice([1, 3, 37, 64, 200, 333])), int(rng.choice([1, 2, 31, 33, 100]))
+    cam = (tuple(rng.uniform(-6, 6, size=3) * rng.choice([0.0, 0.3, 1.0])), float(rng.uniform(-3.2, 3.2)),
+           float(rng.choice([rng.uniform(-1.5, 1.5), np.pi / 2, -np.pi / 2])), float(rng.uniform(0.3, 2.6)), float(rng.choice([0.5, 1.0, 0.4817])))
+    mode = (bool(rng.random() < 0.7), int(rng.integers(1, 4)), int(rng.integers(1, 30)))
+    ramp = "@%#*+=-:. "
+    R.set_strip(0, 0); R.set_ascii(ramp, *mode); R.rt_set_scene(u)
+    out = R.rt_render(cols, rows, *cam)
+    want = orc.rt_render(u, cols, rows, *cam)
+    ok = np.array_equal(out["rgba"], want) and np.array_equal(out["ascii"], orc.quantize(want, cols, rows, ramp, int(mode[0]), mode[1], mode[2]))
+    if not ok:
+        print("MISMATCH ray case %d: %d spheres %d planes %d tris grid %dx%d: rgba %d" % (
+            n, u["uNumS"], u["uNumP"], u["uNumT"], cols, rows, np.count_nonzero(out["rgba"] != want)), flush=True)
+    return ok
 
 
 def main():
@@ -62,9 +111,17 @@ def main():
     bad, t0 = 0, time.time()
     tot_tris = tot_cov = tot_cells = 0
     for n in range(cases):
+        if n % 5 == 4:
+            bad += 0 if rt_check(R, rng, n) else 1
+            continue
         c = make_case(rng)
         R.set_option("path", c["path"]); R.set_option("pool_records", c["pool"]); R.set_option("overlap", c["overlap"])
-        R.set_mesh(c["vbo"], c["idx"]); R.set_camera(c["proj"], c["view"]); R.set_lights(c["lights"])
+        if c["indexed"] is not None:
+            R.set_mesh_indexed(*c["indexed"])
+        else:
+            R.set_mesh(c["vbo"], c["idx"])
+        R.set_mesh_uv(c["uv8"]); R.set_texture(c["atlas"])
+        R.set_camera(c["proj"], c["view"]); R.set_lights(c["lights"])
         R.set_ascii(c["ramp"], *c["mode"])
         rows = c["rows"]
         strip = (0, 0)
@@ -75,7 +132,7 @@ def main():
         for _ in range(reps - 1):
             R.render_async(c["cols"], rows)
         out = R.render(c["cols"], rows, want_ids=True)
-        rgba, depth, ids = orc.render(c["vbo"], c["idx"], c["proj"], c["view"], c["lights"], c["cols"], rows)
+        rgba, depth, ids = orc.render(c["vbo"], c["idx"], c["proj"], c["view"], c["lights"], c["cols"], rows, uv8=c["uv8"], atlas=c["atlas"])
         asc = orc.quantize(rgba, c["cols"], rows, c["ramp"], int(c["mode"][0]), c["mode"][1], c["mode"][2])
         r0, r1 = strip if strip[1] > strip[0] else (0, rows)
         h0, h1 = max(0, r0 - 3), min(rows, r1 + 3)      # rows a strip renders at least (with smoothing halo)
@@ -85,8 +142,8 @@ def main():
         tot_tris += c["idx"].size // 3; tot_cov += int(np.count_nonzero(ids != 0xFFFFFFFF)); tot_cells += c["cols"] * rows
         if not ok:
             bad += 1
-            print("MISMATCH case %d: tris %d grid %dx%d path %d pool %d overlap %d strip %s mode %s: ids %d depth %d rgba %d ascii %d" % (
-                n, c["idx"].size // 3, c["cols"], rows, c["path"], c["pool"], c["overlap"], strip, c["mode"],
+            print("MISMATCH case %d: tris %d grid %dx%d path %d pool %d overlap %d strip %s mode %s textured %s indexed %s: ids %d depth %d rgba %d ascii %d" % (
+                n, c["idx"].size // 3, c["cols"], rows, c["path"], c["pool"], c["overlap"], strip, c["mode"], c["atlas"] is not None and c["atlas"].shape, c["indexed"] is not None,
                 np.count_nonzero(out["ids"][sl] != ids[sl]), np.count_nonzero(out["depth"][sl].view(np.uint32) != depth[sl].view(np.uint32)),
                 np.count_nonzero(out["rgba"][sl] != rgba[sl]), np.count_nonzero(out["ascii"][sl] != asc[sl])), flush=True)
         if n % 25 == 24:
