@@ -1,0 +1,250 @@
+// ascii_stage.h - ASCII stage: quantiser, modal smoothing, text colours, glyph compositing
+// Part of libascii_rast.so; included by ascii_rast.hip (one translation unit), not compiled on its own.
+#pragma once
+
+namespace {
+
+// ASCII stage without smoothing over an RGBA8 grid: alpha 2..254 is a literal code, otherwise the ramp.
+__global__ __launch_bounds__(256) void k_quantize_plain(FrameParams fp, const uint32_t *__restrict__ px,
+                                                        uint8_t *__restrict__ ascii, size_t n) {
+    const size_t p = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t me = px[p];
+    const int a = int(me >> 24);
+    ascii[p] = (a >= 2 && a <= 254)
+                   ? uint8_t(a)
+                   : fp.ramp[ramp_index(int(me & 255u), int((me >> 8) & 255u), int((me >> 16) & 255u), fp.ramp_len)];
+}
+
+// Text colour of the DOM path (js/renderer.js:74-84): channels snapped through a 256-entry table,
+// packed (r << 16) | (g << 8) | b; alpha 2..254 (a UI cell, renderer.js:38-44) is black.
+struct ColorLut {
+    uint8_t q[256];
+};
+
+__global__ __launch_bounds__(256) void k_colors(ColorLut lut, const uint32_t *__restrict__ px, uint32_t *__restrict__ colors, size_t n) {
+    const size_t p = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t me = px[p];
+    const uint32_t a = me >> 24;
+    colors[p] = (a >= 2u && a <= 254u)
+                    ? 0u
+                    : (uint32_t(lut.q[me & 255u]) << 16) | (uint32_t(lut.q[(me >> 8) & 255u]) << 8) | uint32_t(lut.q[(me >> 16) & 255u]);
+}
+
+// Glyph compositing (js/ascii_pass_shader.js:190-230) onto a canvas of cols*cell_w x rows*cell_h pixels,
+// row 0 = top.  A lane produces four consecutive pixels of one canvas row (one 16-byte store): per pixel the glyph's atlas
+// texel (nearest; 2 pixels of tile padding skipped), coverage = cov[alpha] (the shader's pow(alpha,
+// gamma), tabulated on the host), colour = mix(1, tint, coverage) per channel in binary32, bytes rounded
+// like the raster stage's.  A streaming kernel: 4 bytes written per pixel, the per-cell inputs and the
+// atlas are re-read from cache.
+struct PresentParams {
+    int cols, rows, cell_w, cell_h, W, H, atlas_w, tile_w, tile_h;
+    int grayscale, transparent_bg, vec_store;
+    float inv_cell_w;  // 1 / cell_w: (X + 0.5) * inv_cell_w truncates to X / cell_w for every X below 2^20
+};
+
+__global__ __launch_bounds__(256) void k_present(PresentParams pp, const uint32_t *__restrict__ px, const uint8_t *__restrict__ codes,
+                                                 const uint8_t *__restrict__ atlas, const float *__restrict__ cov_of,
+                                                 uint32_t *__restrict__ image) {
+    __shared__ float cov[256], unit[256];  // coverage per alpha byte, colour byte / 255
+    cov[threadIdx.x] = cov_of[threadIdx.x];
+    unit[threadIdx.x] = float(threadIdx.x) / 255.0f;
+    __syncthreads();
+    const int X0 = (int(blockIdx.x) * 256 + int(threadIdx.x)) * 4, Y = int(blockIdx.y);
+    if (X0 >= pp.W) return;
+    const int cy = Y / pp.cell_h, py = Y - cy * pp.cell_h;  // uniform over the workgroup
+    int cx = int((float(X0) + 0.5f) * pp.inv_cell_w), pxl = X0 - cx * pp.cell_w;
+    uint32_t out[4];
+    float tint[3] = {0.0f, 0.0f, 0.0f};
+    const uint8_t *trow = nullptr;
+    int loaded = -1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        out[k] = 0u;
+        if (X0 + k < pp.W) {
+            if (loaded != cx) {
+                const size_t cell = size_t(cy) * pp.cols + cx;
+                const uint32_t cell_px = px[cell];
+                if (!pp.grayscale) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) tint[ch] = unit[(cell_px >> (8 * ch)) & 255u];
+                }
+                const int g = codes[cell];
+                trow = atlas + size_t((g >> 4) * pp.tile_h + 2 + py) * pp.atlas_w + (g & 15) * pp.tile_w + 2;
+                loaded = cx;
+            }
+            const float c = cov[trow[pxl]];
+            if (!(pp.transparent_bg && c <= 0.0f)) {
+                uint32_t v = 0xFF000000u;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    float o = (1.0f - c) + tint[ch] * c;
+                    o = fminf(fmaxf(o, 0.0f), 1.0f);
+                    v |= uint32_t(floorf(o * 255.0f + 0.5f)) << (8 * ch);
+                }
+                out[k] = v;
+            }
+        }
+        if (++pxl == pp.cell_w) { pxl = 0; cx++; }
+    }
+    uint32_t *dst = image + size_t(Y) * pp.W + X0;
+    if (pp.vec_store) {
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (X0 + k < pp.W) dst[k] = out[k];
+    }
+}
+
+// Modal smoothing (ascii_pass_shader.js:77-138,169-185) over rows [row0, row1): a 32x8 tile of cells
+// per workgroup, ramp indices of the tile and its halo of R cells staged in LDS (grid-clamped, as the
+// shader's clampCell does), -1 marking alpha-override cells, which neither vote nor get smoothed.
+// FROM_RGBA: src is an RGBA8 grid (AsciiPass.drawFromBuffer input); otherwise a plane of ramp
+// indices written by k_shade (rendered frames carry no overrides).
+template <int R, bool FROM_RGBA>
+__global__ __launch_bounds__(256) void k_ascii(FrameParams fp, const void *__restrict__ src, uint8_t *__restrict__ ascii) {
+    constexpr int TW = 32 + 2 * R, TH = 8 + 2 * R;
+    __shared__ int16_t tile[TW * TH];
+    const int x0 = int(blockIdx.x) * 32, y0 = fp.row0 + int(blockIdx.y) * 8;
+    for (int k = int(threadIdx.x); k < TW * TH; k += 256) {
+        const int ty = k / TW, tx = k - ty * TW;
+        const int gx = min(max(x0 + tx - R, 0), fp.cols - 1), gy = min(max(y0 + ty - R, 0), fp.rows - 1);
+        const size_t g = size_t(gy) * fp.cols + gx;
+        int val;
+        if (FROM_RGBA) {
+            const uint32_t q = static_cast<const uint32_t *>(src)[g];
+            const int qa = int(q >> 24);
+            val = (qa >= 2 && qa <= 254) ? -1 : ramp_index(int(q & 255u), int((q >> 8) & 255u), int((q >> 16) & 255u), fp.ramp_len);
+        } else {
+            val = static_cast<const uint8_t *>(src)[g];
+        }
+        tile[k] = int16_t(val);
+    }
+    __syncthreads();
+    const int lx = int(threadIdx.x & 31u), ly = int(threadIdx.x >> 5);
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= fp.cols || y >= fp.row1) return;
+    const size_t cell = size_t(y) * fp.cols + x;
+    const int base = tile[(ly + R) * TW + lx + R];
+    if (FROM_RGBA && base < 0) {
+        ascii[cell] = uint8_t(static_cast<const uint32_t *>(src)[cell] >> 24);
+        return;
+    }
+    int nb[(2 * R + 1) * (2 * R + 1) - 1];
+    {
+        int q = 0;
+#pragma unroll
+        for (int dy = -R; dy <= R; dy++)
+#pragma unroll
+            for (int dx = -R; dx <= R; dx++)
+                if (dx != 0 || dy != 0) nb[q++] = tile[(ly + R + dy) * TW + lx + R + dx];
+    }
+    int cand = -1, cnt = 0, votes = 0;  // Boyer-Moore candidate in shader order, then its true vote count
+#pragma unroll
+    for (int q = 0; q < (2 * R + 1) * (2 * R + 1) - 1; q++) {
+        const int ni = nb[q];
+        if (ni < 0) continue;
+        if (cnt == 0) { cand = ni; cnt = 1; }
+        else if (ni == cand) cnt += 1;
+        else cnt -= 1;
+    }
+#pragma unroll
+    for (int q = 0; q < (2 * R + 1) * (2 * R + 1) - 1; q++) votes += (nb[q] >= 0 && nb[q] == cand) ? 1 : 0;
+    const int fin = (cand >= 0 && votes >= fp.mode_thresh && cand != base) ? cand : base;
+    ascii[cell] = (fin >= 0 && fin < fp.ramp_len) ? fp.ramp[fin] : uint8_t(32);
+}
+
+// Modal smoothing over a plane of ramp indices (what rendered frames produce: no override cells).
+// A workgroup takes 128 x 8 cells, a lane four consecutive cells of one row.  The tile and its halo are
+// staged as bytes with rows padded so that a lane's window (its four cells and R neighbours on either
+// side) is three aligned dwords per row: 3 * (2R + 1) LDS reads serve four cells, and the neighbours are
+// byte fields of registers.  Same Boyer-Moore order and vote rule as k_ascii.
+template <int R>
+__global__ __launch_bounds__(256) void k_ascii_plane(FrameParams fp, const uint8_t *__restrict__ src, uint8_t *__restrict__ ascii) {
+    constexpr int TWD = 34, TH = 8 + 2 * R;  // dwords per tile row: 4 bytes of left halo, 128 cells, 4 of right halo
+    __shared__ uint32_t tile[TWD * TH];
+    __shared__ uint8_t ramp[AR_MAX_RAMP];
+    const int x0 = int(blockIdx.x) * 128, y0 = fp.row0 + int(blockIdx.y) * 8;
+    ramp[threadIdx.x] = fp.ramp[threadIdx.x];
+    const bool cols4 = (fp.cols & 3) == 0;
+    for (int k = int(threadIdx.x); k < TWD * TH; k += 256) {
+        const int ty = k / TWD, td = k - ty * TWD;
+        const int gy = min(max(y0 + ty - R, 0), fp.rows - 1);
+        const int gx = x0 - 4 + 4 * td;  // column of the dword's first byte
+        const uint8_t *row = src + size_t(gy) * fp.cols;
+        uint32_t v;
+        if (cols4 && gx >= 0 && gx + 3 < fp.cols) {
+            v = *reinterpret_cast<const uint32_t *>(row + gx);
+        } else {
+            v = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) v |= uint32_t(row[min(max(gx + q, 0), fp.cols - 1)]) << (8 * q);
+        }
+        tile[k] = v;
+    }
+    __syncthreads();
+    const int lx = int(threadIdx.x & 31u), ly = int(threadIdx.x >> 5);
+    const int x = x0 + 4 * lx, y = y0 + ly;
+    if (x >= fp.cols || y >= fp.row1) return;
+    uint32_t w[2 * R + 1][3];
+#pragma unroll
+    for (int dy = -R; dy <= R; dy++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) w[dy + R][q] = tile[(ly + R + dy) * TWD + lx + q];
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        // byte p of a window row is column x - 4 + p; cell j sits at p = 4 + j
+        int cand = -1, cnt = 0, votes = 0;
+#pragma unroll
+        for (int dy = -R; dy <= R; dy++)
+#pragma unroll
+            for (int dx = -R; dx <= R; dx++) {
+                if (dx == 0 && dy == 0) continue;
+                const int p = 4 + j + dx;
+                const int ni = int((w[dy + R][p >> 2] >> (8 * (p & 3))) & 255u);
+                cand = cnt == 0 ? ni : cand;
+                cnt += ni == cand ? 1 : -1;
+            }
+#pragma unroll
+        for (int dy = -R; dy <= R; dy++)
+#pragma unroll
+            for (int dx = -R; dx <= R; dx++) {
+                if (dx == 0 && dy == 0) continue;
+                const int p = 4 + j + dx;
+                votes += int((w[dy + R][p >> 2] >> (8 * (p & 3))) & 255u) == cand ? 1 : 0;
+            }
+        const int base = int((w[R][(4 + j) >> 2] >> (8 * ((4 + j) & 3))) & 255u);
+        const int fin = (votes >= fp.mode_thresh && cand != base) ? cand : base;
+        out |= uint32_t(fin < fp.ramp_len ? ramp[fin] : uint8_t(32)) << (8 * j);
+    }
+    uint8_t *dst = ascii + size_t(y) * fp.cols + x;
+    if (cols4) {
+        *reinterpret_cast<uint32_t *>(dst) = out;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (x + j < fp.cols) dst[j] = uint8_t(out >> (8 * j));
+    }
+}
+
+template <bool FROM_RGBA>
+void launch_ascii(const FrameParams &fp, const void *src, uint8_t *ascii, hipStream_t stream) {
+    const int radius = fp.mode_radius < 1 ? 1 : (fp.mode_radius > 3 ? 3 : fp.mode_radius);  // shader clamps to 1..3
+    if constexpr (!FROM_RGBA) {
+        const dim3 grid((fp.cols + 127) / 128, (fp.row1 - fp.row0 + 7) / 8);
+        const uint8_t *plane = static_cast<const uint8_t *>(src);
+        if (radius == 1) k_ascii_plane<1><<<grid, 256, 0, stream>>>(fp, plane, ascii);
+        else if (radius == 2) k_ascii_plane<2><<<grid, 256, 0, stream>>>(fp, plane, ascii);
+        else k_ascii_plane<3><<<grid, 256, 0, stream>>>(fp, plane, ascii);
+    } else {
+        const dim3 grid((fp.cols + 31) / 32, (fp.row1 - fp.row0 + 7) / 8);
+        if (radius == 1) k_ascii<1, FROM_RGBA><<<grid, 256, 0, stream>>>(fp, src, ascii);
+        else if (radius == 2) k_ascii<2, FROM_RGBA><<<grid, 256, 0, stream>>>(fp, src, ascii);
+        else k_ascii<3, FROM_RGBA><<<grid, 256, 0, stream>>>(fp, src, ascii);
+    }
+}
+
+}  // namespace

@@ -1,0 +1,393 @@
+// context.h - the renderer context (ar_ctx), its buffers and streams, and the per-frame enqueue
+// Part of libascii_rast.so; included by ascii_rast.hip (one translation unit), not compiled on its own.
+#pragma once
+
+namespace {
+
+thread_local char g_create_error[256] = "";
+
+}  // namespace
+
+struct ar_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;   // stream of frames that do not overlap, of quantize / present and of copies: own_stream
+                                    // or the caller's (ar_set_stream)
+    hipStream_t own_stream = nullptr;
+    hipStream_t fstream[kSets] = {};  // overlapped frames: frame f runs entirely on fstream[f % kSets]; [0] is own_stream
+    bool overlapped_in_flight = false;  // an overlapped frame was enqueued since the last full synchronisation
+    bool ext_stream = false;        // stream is the caller's: every kernel goes there, frames do not overlap
+    uint8_t *ascii_target = nullptr;  // caller's device buffer for the ASCII plane (ar_set_ascii_target), else d_ascii
+    int target_row = 0;               // frame row stored at ascii_target
+    int overlap = 2;                // 0: frames one after the other on `stream`; 1, 2: consecutive frames alternate streams
+    hipEvent_t ev_out[kSets + 1] = {};  // outputs complete on each frame stream / on `stream` (ar_stream_wait_frame)
+    hipEvent_t ev_ext = nullptr;    // a caller's stream has consumed the outputs (ar_frame_wait_stream)
+    float *d_vbo = nullptr;
+    uint32_t *d_idx = nullptr;
+    uint32_t n_verts = 0, n_tris = 0;
+    float proj[16], view[16];
+    FrameParams fp;
+    int strip0 = 0, strip1 = 0;
+    int cols = 0, rows = 0;  // size of the current targets
+    uint64_t *d_vis[kSets] = {};  // global key buffers ([0] direct path; tiled path: overflow keys of the frame's set)
+    // outputs, per buffer set while frames overlap (frames that do not overlap always use set 0)
+    uint8_t *d_rgba[kSets] = {};
+    float *d_depth[kSets] = {};
+    uint8_t *d_ascii[kSets] = {};
+    int last_oset = 0;           // output set of the most recent frame
+    uint8_t *d_ridx[kSets] = {};  // ramp index per cell (input of the smoothing pass)
+    uint32_t *d_ids[kSets] = {};  // winner per cell, allocated when id output is switched on
+    bool want_ids = false;
+    bool vis_clean = false;      // every key of d_vis[*] is "background" (the consuming kernels restore this each frame)
+    TriRec *d_medium = nullptr, *d_large = nullptr;
+    uint32_t *d_counters = nullptr;  // [0..1] live queue counters, [2..3] those of the last frame
+    // tiled path
+    int path = 0;                    // 0: tiled when the grid allows it, 1: always the direct path
+    uint32_t pool_cap_option = 0;    // 0: sized from the triangle count
+    float *d_tripos = nullptr;       // 9 planes x tripos_stride floats: triangle positions
+    size_t tripos_stride = 0;
+    float *d_triattr = nullptr;      // n_tris x 24 floats: the three vertices' normals and colours
+    // everything the binning kernels write, per buffer set
+    BinRec *d_records[kSets] = {};  // 2 x n_tris setup record slots, filled densely per k_setup workgroup
+    uint8_t *d_flat = nullptr;       // n_tris flag bytes: kFlagFlat | kFlagTextured
+    void *d_rt = nullptr;            // ray backend: the scene arrays of ar_rt_set_scene in one allocation
+    RtScene rt_scene = {};           // counts and device pointers into d_rt
+    bool rt_has_scene = false;
+    uint4 *d_triuv = nullptr;        // n_tris texel-coordinate rows (ar_set_mesh_uv), else null
+    uint32_t *d_atlas = nullptr;     // atlas texels (ar_set_texture), else null
+    int atlas_w = 0, atlas_h = 0;
+    uint2 *d_surv[kSets] = {};  // per k_setup workgroup: cell ranges of its surviving sub-triangles
+    uint32_t *d_surv_count[kSets] = {};
+    uint32_t *d_dircount[kSets] = {};  // per k_setup workgroup: entries per bin (+ scan scratch)
+    size_t group_cap = 0, dircount_cap = 0;
+    uint32_t *d_entries[kSets] = {};  // (record slot, tile mask) entries grouped by bin
+    uint32_t pool_cap = 0;
+    BinState *d_state = nullptr;     // kSets blocks
+    uint32_t frame = 0;              // tiled frames enqueued so far
+    bool last_tiled = false;
+    uint8_t *d_q_rgba = nullptr, *d_q_ascii = nullptr;
+    size_t q_cells = 0;
+    uint32_t *d_q_colors = nullptr;
+    size_t qc_cells = 0;
+    uint8_t *d_p_atlas = nullptr; float *d_p_cov = nullptr; uint32_t *d_p_image = nullptr;  // ar_present scratch
+    size_t p_atlas_bytes = 0, p_pixels = 0;
+    bool rendered = false;
+    bool profiling = false;
+    struct Stamp { hipEvent_t a, b; int slot; };
+    std::vector<Stamp> stamps;
+    std::vector<hipEvent_t> free_events;
+    char err[256] = "";
+};
+
+namespace {
+
+int fail(ar_ctx *ctx, int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx ? ctx->err : g_create_error, 256, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define AR_HIP(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) return fail(ctx, AR_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+void matmul_pv(const float *P, const float *V, float *PV) {
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++)
+            PV[c * 4 + r] = ((P[0 * 4 + r] * V[c * 4 + 0] + P[1 * 4 + r] * V[c * 4 + 1]) + P[2 * 4 + r] * V[c * 4 + 2]) +
+                            P[3 * 4 + r] * V[c * 4 + 3];
+}
+
+struct Stamper {  // brackets one launch with events when profiling is on
+    ar_ctx *ctx;
+    hipEvent_t a = nullptr, b = nullptr;
+    int slot;
+    hipStream_t stream;
+    Stamper(ar_ctx *c, int s, hipStream_t st = nullptr) : ctx(c), slot(s), stream(st ? st : c->stream) {
+        if (!ctx->profiling) return;
+        a = take(); b = take();
+        if (a) (void)hipEventRecord(a, stream);
+    }
+    ~Stamper() {
+        if (!ctx->profiling || !a || !b) return;
+        (void)hipEventRecord(b, stream);
+        ctx->stamps.push_back({a, b, slot});
+    }
+    hipEvent_t take() {
+        if (!ctx->free_events.empty()) { hipEvent_t e = ctx->free_events.back(); ctx->free_events.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+    }
+};
+
+int sync_streams(ar_ctx *ctx) {
+    ctx->overlapped_in_flight = false;
+    for (int k = 0; k < kSets; k++) AR_HIP(ctx, hipStreamSynchronize(ctx->fstream[k]));
+    if (ctx->stream != ctx->own_stream) AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int free_targets(ar_ctx *ctx) {
+    for (int k = 0; k < kSets; k++) {
+        (void)hipFree(ctx->d_vis[k]); (void)hipFree(ctx->d_rgba[k]); (void)hipFree(ctx->d_depth[k]); (void)hipFree(ctx->d_ascii[k]);
+        (void)hipFree(ctx->d_ridx[k]); (void)hipFree(ctx->d_ids[k]);
+        ctx->d_vis[k] = nullptr; ctx->d_rgba[k] = nullptr; ctx->d_depth[k] = nullptr; ctx->d_ascii[k] = nullptr;
+        ctx->d_ridx[k] = nullptr; ctx->d_ids[k] = nullptr;
+    }
+    ctx->cols = ctx->rows = 0;
+    ctx->rendered = false;
+    ctx->vis_clean = false;
+    ctx->last_oset = 0;
+    return 0;
+}
+
+int ensure_targets(ar_ctx *ctx, int cols, int rows) {
+    const size_t n = size_t(cols) * rows;
+    if (!(ctx->d_vis[0] && ctx->cols == cols && ctx->rows == rows)) {
+        int rc = sync_streams(ctx);
+        if (rc) return rc;
+        free_targets(ctx);
+        for (int k = 0; k < kSets; k++) {
+            AR_HIP(ctx, hipMalloc(&ctx->d_vis[k], n * sizeof(uint64_t)));
+            AR_HIP(ctx, hipMalloc(&ctx->d_rgba[k], n * 4));
+            AR_HIP(ctx, hipMalloc(&ctx->d_depth[k], n * sizeof(float)));
+            AR_HIP(ctx, hipMalloc(&ctx->d_ascii[k], n));
+            AR_HIP(ctx, hipMalloc(&ctx->d_ridx[k], n));
+            // rows outside a strip are never written by the kernels: give them defined contents once
+            AR_HIP(ctx, hipMemsetAsync(ctx->d_rgba[k], 0, n * 4, ctx->stream));
+            AR_HIP(ctx, hipMemsetAsync(ctx->d_depth[k], 0, n * sizeof(float), ctx->stream));
+            AR_HIP(ctx, hipMemsetAsync(ctx->d_ascii[k], 0, n, ctx->stream));
+            AR_HIP(ctx, hipMemsetAsync(ctx->d_ridx[k], 0, n, ctx->stream));
+        }
+        AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->cols = cols; ctx->rows = rows;
+    }
+    if (ctx->want_ids && !ctx->d_ids[0]) {
+        int rc = sync_streams(ctx);
+        if (rc) return rc;
+        for (int k = 0; k < kSets; k++) {
+            AR_HIP(ctx, hipMalloc(&ctx->d_ids[k], n * sizeof(uint32_t)));
+            AR_HIP(ctx, hipMemsetAsync(ctx->d_ids[k], 0xFF, n * sizeof(uint32_t), ctx->stream));
+        }
+        AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+// Waits for the frames in flight and releases the current mesh with everything derived from it.
+int drop_mesh(ar_ctx *ctx) {
+    int rc = sync_streams(ctx);
+    if (rc) return rc;
+    (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr);
+    (void)hipFree(ctx->d_flat); (void)hipFree(ctx->d_triuv);
+    for (int k = 0; k < kSets; k++) { (void)hipFree(ctx->d_records[k]); ctx->d_records[k] = nullptr; }
+    ctx->d_vbo = nullptr; ctx->d_idx = nullptr; ctx->d_tripos = nullptr; ctx->d_triattr = nullptr;
+    ctx->d_flat = nullptr; ctx->d_triuv = nullptr;  // texel coordinates belong to the mesh they were given for
+    ctx->n_verts = 0; ctx->n_tris = 0;
+    return 0;
+}
+
+// d_vbo / d_idx hold the new mesh: derive the streams of the tiled path (positions, attribute rows, flag
+// bytes) and allocate its record slots.
+int finish_mesh(ar_ctx *ctx, uint32_t n_verts, uint32_t n_tris) {
+    ctx->tripos_stride = (size_t(n_tris) + 63) / 64 * 64;
+    AR_HIP(ctx, hipMalloc(&ctx->d_tripos, 9 * ctx->tripos_stride * sizeof(float)));
+    AR_HIP(ctx, hipMalloc(&ctx->d_triattr, size_t(n_tris) * 24 * sizeof(float)));
+    for (int k = 0; k < kSets; k++) AR_HIP(ctx, hipMalloc(&ctx->d_records[k], 2 * size_t(n_tris) * sizeof(BinRec)));
+    AR_HIP(ctx, hipMalloc(&ctx->d_flat, size_t(n_tris)));
+    k_tristream<<<(n_tris + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_vbo, ctx->d_idx, n_verts, n_tris, ctx->tripos_stride, ctx->d_tripos,
+                                                              ctx->d_triattr, ctx->d_flat);
+    AR_HIP(ctx, hipGetLastError());
+    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_verts = n_verts; ctx->n_tris = n_tris;
+    return 0;
+}
+
+// Frames whose caller does not wait for them right away (may_overlap) run entirely on one of kSets frame
+// streams, frame f on stream f % kSets, and every buffer a frame writes exists kSets times: consecutive
+// frames share the GPU without a single cross-stream event (each of which costs the host about as much as
+// two kernel launches), and frame f + kSets follows frame f on the same stream, which is all the ordering
+// the reuse of a buffer set needs.
+int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
+    if (cols <= 0 || rows <= 0 || size_t(cols) * rows > (size_t(1) << 31))
+        return fail(ctx, AR_E_ARG, "ar_render: bad grid %d x %d", cols, rows);
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_targets(ctx, cols, rows);
+    if (rc) return rc;
+    if (ctx->n_tris == 0 || !ctx->d_vbo || !ctx->d_idx) return 0;  // raster.js:274: nothing to draw
+
+    FrameParams &fp = ctx->fp;
+    fp.cols = cols; fp.rows = rows;
+    fp.hw = float(cols) * 0.5f; fp.hh = float(rows) * 0.5f;
+    fp.n_tris = ctx->n_tris; fp.n_verts = ctx->n_verts;
+    fp.want_ids = ctx->want_ids ? 1 : 0;
+    int row0 = 0, row1 = rows;
+    if (ctx->strip1 > ctx->strip0) {
+        if (ctx->strip1 > rows) return fail(ctx, AR_E_ARG, "strip [%d,%d) exceeds %d rows", ctx->strip0, ctx->strip1, rows);
+        row0 = ctx->strip0; row1 = ctx->strip1;
+    }
+    const int halo = fp.mode_on == 1 ? 3 : 0;  // smoothing reads up to 3 rows beyond the strip
+    fp.row0 = row0; fp.row1 = row1;
+    fp.ya = row0 - halo < 0 ? 0 : row0 - halo;
+    fp.yb = row1 + halo > rows ? rows : row1 + halo;
+    matmul_pv(ctx->proj, ctx->view, fp.pv);
+    // texturing needs texel coordinates, an atlas, and more than one texel either way (shader_utils.js:94)
+    const bool textured = ctx->d_triuv && ctx->d_atlas && ctx->atlas_w > 1 && ctx->atlas_h > 1;
+    fp.tex_w = textured ? ctx->atlas_w : 0;
+    fp.tex_h = textured ? ctx->atlas_h : 0;
+
+    const size_t strip_cells = size_t(fp.yb - fp.ya) * cols;
+    const unsigned cell_blocks = unsigned((strip_cells + 255) / 256);
+    fp.ntx = (cols + kTileW - 1) / kTileW;
+    fp.nty = (fp.yb - fp.ya + kTileH - 1) / kTileH;
+    fp.bshift = 1;  // per-tile bins (0) shorten k_tile's filter but cost as much again in the binning kernels
+    fp.nbx = (fp.ntx + (1 << fp.bshift) - 1) >> fp.bshift;
+    fp.nby = (fp.nty + (1 << fp.bshift) - 1) >> fp.bshift;
+    const size_t nt = size_t(fp.ntx) * fp.nty;
+    const size_t nbins = size_t(fp.nbx) * fp.nby;
+    const bool tiled = ctx->path == 0 && nt <= size_t(kMaxTiles) && nbins <= size_t(kMaxBins) && cols <= 65535 &&
+                       rows <= 65535 && ctx->d_tripos && ctx->n_tris <= (kEntryLocMask >> 1) - 65536u;  // slots fit an entry
+    const int set = int(ctx->frame % unsigned(kSets));  // buffer set of this frame (tiled path)
+    const bool overlap = tiled && may_overlap && !ctx->ext_stream && ctx->overlap != 0;
+    if (!overlap && ctx->overlapped_in_flight) {  // frames still running on the frame streams
+        rc = sync_streams(ctx);
+        if (rc) return rc;
+    }
+    if (overlap) ctx->overlapped_in_flight = true;
+    hipStream_t fs = overlap ? ctx->fstream[set] : ctx->stream;  // the stream of this frame
+    const int oset = overlap ? set : 0;                          // its output buffers
+    uint8_t *ascii_out = ctx->ascii_target ? ctx->ascii_target - ptrdiff_t(ctx->target_row) * cols : ctx->d_ascii[oset];
+    if (tiled != ctx->last_tiled && ctx->rendered) {
+        // the two paths share the key buffers and do not order themselves against each other's streams
+        rc = sync_streams(ctx);
+        if (rc) return rc;
+    }
+    if (tiled) {
+        // one triangle per k_setup lane and pass; more passes only beyond kMaxGroups workgroups
+        uint32_t chunk = (fp.n_tris + kMaxGroups - 1) / kMaxGroups;
+        chunk = (chunk + kSetupThreads - 1) / kSetupThreads * kSetupThreads;
+        fp.chunk = chunk;
+        fp.n_groups = (fp.n_tris + chunk - 1) / chunk;
+        fp.frame = ctx->frame;
+        fp.set = set;
+        const uint32_t want_cap = ctx->pool_cap_option ? ctx->pool_cap_option : 2u * fp.n_tris + 65536u;
+        if (!ctx->d_entries[0] || ctx->pool_cap != want_cap) {
+            rc = sync_streams(ctx);
+            if (rc) return rc;
+            for (int k = 0; k < kSets; k++) { (void)hipFree(ctx->d_entries[k]); ctx->d_entries[k] = nullptr; }
+            ctx->pool_cap = 0;
+            for (int k = 0; k < kSets; k++) AR_HIP(ctx, hipMalloc(&ctx->d_entries[k], size_t(want_cap) * sizeof(uint32_t)));
+            ctx->pool_cap = want_cap;
+        }
+        const size_t want_groups = size_t(fp.n_groups) * 2 * chunk;
+        if (!ctx->d_surv[0] || ctx->group_cap < want_groups) {
+            rc = sync_streams(ctx);
+            if (rc) return rc;
+            for (int k = 0; k < kSets; k++) {
+                (void)hipFree(ctx->d_surv[k]); (void)hipFree(ctx->d_surv_count[k]);
+                ctx->d_surv[k] = nullptr; ctx->d_surv_count[k] = nullptr;
+            }
+            ctx->group_cap = 0;
+            for (int k = 0; k < kSets; k++) {
+                AR_HIP(ctx, hipMalloc(&ctx->d_surv[k], want_groups * sizeof(uint2)));
+                AR_HIP(ctx, hipMalloc(&ctx->d_surv_count[k], (size_t(kMaxGroups) + 1) * sizeof(uint32_t)));
+            }
+            ctx->group_cap = want_groups;
+        }
+        const size_t want_dir = size_t(fp.n_groups) * nbins;
+        if (!ctx->d_dircount[0] || ctx->dircount_cap < want_dir) {
+            rc = sync_streams(ctx);
+            if (rc) return rc;
+            for (int k = 0; k < kSets; k++) { (void)hipFree(ctx->d_dircount[k]); ctx->d_dircount[k] = nullptr; }
+            ctx->dircount_cap = 0;
+            for (int k = 0; k < kSets; k++) AR_HIP(ctx, hipMalloc(&ctx->d_dircount[k], (want_dir + 32 * size_t(kMaxBins)) * sizeof(uint32_t)));
+            ctx->dircount_cap = want_dir;
+        }
+    }
+    const bool was_clean = ctx->vis_clean;
+    ctx->vis_clean = false;  // stays false if anything below fails: the next frame then starts from scratch
+    if (!was_clean) {
+        // first frame on these targets (or after a failed one).  In steady state every kernel that
+        // consumes a visibility key or a queue counter puts it back to its idle value, so no per-frame
+        // clear is needed.
+        rc = sync_streams(ctx);
+        if (rc) return rc;
+        AR_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+        AR_HIP(ctx, hipMemsetAsync(ctx->d_state, 0, kSets * sizeof(BinState), ctx->stream));
+        {
+            Stamper s(ctx, K_CLEAR);
+            for (int k = 0; k < kSets; k++) k_clear<<<2048, 256, 0, ctx->stream>>>(ctx->d_vis[k], 0, size_t(cols) * rows);
+        }
+        AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (tiled) {
+        uint32_t *dircount = ctx->d_dircount[set];
+        uint32_t *blocksum = dircount + ctx->dircount_cap, *boff = blocksum + 16 * size_t(kMaxBins);
+        {
+            Stamper s(ctx, K_SETUP, fs);
+            k_setup<<<fp.n_groups, kSetupThreads, 0, fs>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_flat, ctx->d_records[set],
+                                                         ctx->d_surv[set], ctx->d_surv_count[set], dircount);
+        }
+        {
+            Stamper s(ctx, K_BINSCAN, fs);
+            k_binscan<<<dim3(unsigned((nbins + 63) / 64), 16), 1024, 0, fs>>>(fp, dircount, blocksum);
+        }
+        {
+            Stamper s(ctx, K_BINOFF, fs);
+            k_binoffsets<<<1, 1024, 0, fs>>>(fp, blocksum, boff, ctx->d_state, ctx->pool_cap);
+        }
+        {
+            Stamper s(ctx, K_FILL, fs);
+            k_fill<<<fp.n_groups, kSetupThreads, 0, fs>>>(fp, ctx->d_records[set], ctx->d_surv[set], ctx->d_surv_count[set], dircount, boff,
+                                                        ctx->d_state, ctx->d_entries[set], ctx->pool_cap, ctx->d_vis[set]);
+        }
+        {
+            Stamper s(ctx, K_TILE, fs);
+            const unsigned grid = unsigned((nbins + 7) / 8 * 8) << (2 * fp.bshift);
+            auto kernel = textured ? k_tile<true> : k_tile<false>;
+            kernel<<<grid, 256, 0, fs>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_tripos, ctx->tripos_stride, ctx->d_triuv,
+                                         ctx->d_atlas, ctx->d_records[set], ctx->d_entries[set], ctx->pool_cap, ctx->d_state,
+                                         ctx->d_vis[set], ctx->d_rgba[oset], ctx->d_depth[oset], ascii_out, ctx->d_ridx[set],
+                                         ctx->d_ids[oset]);
+        }
+        ctx->frame++;
+    } else {
+        {
+            Stamper s(ctx, K_RASTER);
+            k_raster<<<(fp.n_tris + 255) / 256, 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_vis[0], ctx->d_medium,
+                                                                      ctx->d_large, ctx->d_counters);
+        }
+        {
+            Stamper s(ctx, K_MEDIUM);
+            k_raster_medium<<<512, 256, 0, ctx->stream>>>(fp, ctx->d_vis[0], ctx->d_medium, ctx->d_counters);
+        }
+        {
+            Stamper s(ctx, K_LARGE);
+            dim3 grid((cols + 15) / 16, (fp.yb - fp.ya + 15) / 16);
+            k_raster_large<<<grid, 256, 0, ctx->stream>>>(fp, ctx->d_vis[0], ctx->d_large, ctx->d_counters);
+        }
+        {
+            Stamper s(ctx, K_SHADE);
+            k_shade<<<cell_blocks, 256, 0, ctx->stream>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triuv, ctx->d_atlas, ctx->d_vis[0],
+                                                         ctx->d_rgba[0], ctx->d_depth[0],
+                                                         ascii_out, ctx->d_ridx[0], ctx->d_ids[0], ctx->d_counters);
+        }
+    }
+    if (fp.mode_on == 1) {
+        Stamper s(ctx, K_ASCII, fs);
+        // a textured frame can hold ASCII overrides in its alpha bytes, which the plane of ramp indices cannot express
+        if (textured) launch_ascii<true>(fp, ctx->d_rgba[oset], ascii_out, fs);
+        else launch_ascii<false>(fp, ctx->d_ridx[tiled ? set : 0], ascii_out, fs);
+    }
+    AR_HIP(ctx, hipGetLastError());
+    ctx->vis_clean = true;
+    ctx->rendered = true;
+    ctx->last_tiled = tiled;
+    ctx->last_oset = oset;
+    return 0;
+}
+
+}  // namespace

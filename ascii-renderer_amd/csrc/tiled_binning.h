@@ -1,0 +1,421 @@
+// tiled_binning.h - tiled path, first half: mesh streams, triangle setup, bin scans, entry fill
+// Part of libascii_rast.so; included by ascii_rast.hip (one translation unit), not compiled on its own.
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Tiled path: sub-triangles are binned to screen bins of 2x2 tiles, each 64x32-cell tile is resolved
+// in LDS.
+//
+//   k_tristream (at mesh upload) gathers, per triangle, the three positions into nine planes of
+//             n_tris floats (36 contiguous, coalesced bytes per triangle for the per-frame pass),
+//             the three vertices' normals and colours into one 96-byte row (one gather per shaded
+//             cell instead of index -> vertex chasing) and a flag telling whether the triangle is
+//             flat (identical normal and colour at its three vertices).
+//   k_setup   one pass over the positions, one triangle per lane and pass: transform, near clip,
+//             cull, cell range.  Every sub-triangle that can produce fragments gets a 64-byte setup
+//             record in the workgroup's block of record slots (dense, in triangle order), a 16-byte
+//             tuple for k_fill, and is counted into the workgroup's LDS histogram over bins, which
+//             is then published as one row of the count table.
+//   k_binscan column-wise exclusive prefix of the count table over the k_setup workgroups (in
+//             place, two levels) and per-row-block bin totals: every (workgroup, bin) pair gets a
+//             fixed slice of the bin's entry array without a single global atomic.
+//   k_binoffsets  bin totals, start of each bin's entry array (exclusive scan), row-block offsets,
+//             overflow flag.
+//   k_fill    every k_setup workgroup's survivors become one entry (record slot, mask of the bin's
+//             tiles the cell range touches) per (survivor, bin), written into that workgroup's slice.
+//   k_tile    one workgroup per tile: filters its bin's entries by mask bit into an LDS work list,
+//             rasterises those records into a 2048-entry LDS key tile with LDS atomic min (small
+//             cell ranges: one lane per record; large ones: all lanes sweep the range), then shades
+//             the covered cells and writes the tile's RGBA / depth / ramp-index rows.  Visibility
+//             keys never touch HBM.
+// If the entry pool cannot hold a bin, the sub-triangles touching that bin are rasterised straight
+// into a global key buffer by k_fill, k_binoffsets raises the frame's overflow flag and k_tile merges
+// that buffer in.
+// Everything a frame writes exists kSets times, so that consecutive frames can overlap: see
+// enqueue_frame.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSets = 3;               // frames in flight: every per-frame buffer exists kSets times
+constexpr int kTileShiftH = 5;          // log2 of the tile height
+constexpr int kTileW = 64, kTileH = 1 << kTileShiftH, kTileCells = kTileW * kTileH;  // (a tile is one wavefront wide)
+constexpr int kMaxTiles = 8000;       // tiles per frame the tiled path accepts
+constexpr int kMaxBins = 2048;        // >= kMaxTiles / 4 for any tile-grid shape the path accepts
+constexpr int kSetupThreads = 256;    // k_setup / k_fill workgroup size
+constexpr uint32_t kMaxGroups = 1024;  // k_setup workgroups (rows of the count table)
+constexpr int kTileBigMax = 512;      // per-tile list of records swept cooperatively
+constexpr int kTileSmallCells = 64;   // cell-range area (inside the tile) one lane scans itself
+constexpr int kTileListMax = 2048;    // ids staged in LDS between the filter and the raster step
+constexpr int kEntryMaskShift = 28;   // a bin entry is (record slot) | (mask of the bin's 2x2 tiles) << 28
+constexpr uint32_t kEntryLocMask = (1u << kEntryMaskShift) - 1u;
+constexpr int kFilterBatch = 4;       // bin entries a k_tile lane loads per filter step
+constexpr uint32_t kFlagClipped = 1u; // record produced by the near-plane clip (vertices differ from the mesh's)
+constexpr uint32_t kFlagFlat = 2u;    // the triangle's three vertices carry identical normal and colour
+constexpr uint32_t kFlagTextured = 4u;  // the triangle samples the atlas (set from its texel-coordinate row)
+
+struct __align__(16) BinRec {
+    float X[3], Y[3], W[3], Z[3];
+    uint32_t id;              // 2*triangle + sub-triangle
+    uint16_t i0, i1, j0, j1;  // inclusive cell range, GL window rows (y up)
+    uint32_t flags;           // kFlagClipped | kFlagFlat | kFlagTextured
+};
+static_assert(sizeof(BinRec) == 64, "bin records are four 16-byte loads");
+
+// Per-frame binning state; one block per buffer set.
+struct BinState {
+    uint32_t total[kMaxBins];
+    uint32_t start[kMaxBins];   // exclusive scan of total (k_binoffsets)
+    uint32_t overflow;          // some bin did not fit the entry pool
+    uint32_t n_entries;         // sum of total
+    uint32_t pad[2];
+};
+
+// Exclusive prefix sum of v over the lanes of the workgroup (lane order); total = sum of all.
+// NW = wavefronts per workgroup.
+template <int NW>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s_wave, uint32_t &total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t n = __shfl_up(incl, d);
+        if (lane >= uint32_t(d)) incl += n;
+    }
+    if (lane == 63u) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const uint32_t x = s_wave[w];
+        if (uint32_t(w) < wave) off += x;
+        tot += x;
+    }
+    total = tot;
+    __syncthreads();
+    return off + incl - v;
+}
+
+// Per triangle: positions -> planes pos[k*stride + t] (k = 3*vertex + axis); normal and colour of each
+// vertex -> attr[t*24 + 8*v ..] = (nx, ny, nz, r, g, b, 0, 0), so a vertex is one 16-byte plus one
+// 8-byte load; flat[t] = kFlagFlat when the three normals and the three colours are identical.
+// A triangle that names a vertex outside the buffer gets NaN positions, which every later stage rejects.
+__global__ __launch_bounds__(256) void k_tristream(const float *__restrict__ vbo, const uint32_t *__restrict__ idx,
+                                                   uint32_t n_verts, uint32_t n_tris, size_t stride,
+                                                   float *__restrict__ pos, float *__restrict__ attr,
+                                                   uint8_t *__restrict__ flat) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_tris) return;
+    float a[3][9];
+    bool all_ok = true;
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+        const uint32_t vi = idx[3 * size_t(t) + v];
+        const bool ok = vi < n_verts;
+        all_ok = all_ok && ok;
+        const float *p = vbo + size_t(ok ? vi : 0u) * 9;
+#pragma unroll
+        for (int q = 0; q < 9; q++) a[v][q] = ok ? p[q] : 0.0f;
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) pos[size_t(3 * v + ax) * stride + t] = ok ? p[ax] : __builtin_nanf("");
+    }
+    float4 *row = reinterpret_cast<float4 *>(attr) + size_t(t) * 6;
+    bool is_flat = all_ok;
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+        row[2 * v] = make_float4(a[v][3], a[v][4], a[v][5], a[v][6]);
+        row[2 * v + 1] = make_float4(a[v][7], a[v][8], 0.0f, 0.0f);
+#pragma unroll
+        for (int q = 3; q < 9; q++) is_flat = is_flat && (__float_as_uint(a[v][q]) == __float_as_uint(a[0][q]));
+    }
+    flat[t] = is_flat ? uint8_t(kFlagFlat) : uint8_t(0);
+}
+
+// Indexed mesh -> the reference's unshared, flat-shaded vertex buffer (what _rebuildGeometry's pushTri emits
+// per triangle, raster.js:158-169,222-236): one lane per triangle gathers its three positions, takes the
+// normal normalize(cross(b - a, c - a)) in binary64 - every product and sum rounded on its own, as the
+// JavaScript expression is - with (0, 1, 0) when its length is <= 1e-8, and writes three vertices of
+// (position, normal, colour) plus the indices 3t, 3t+1, 3t+2.  A vertex index beyond the position array
+// yields NaN positions (what a typed array yields there), which every later stage rejects.
+__global__ __launch_bounds__(256) void k_build_vbo(const float *__restrict__ positions, uint32_t n_verts,
+                                                   const uint32_t *__restrict__ indices, uint32_t n_tris,
+                                                   const float *__restrict__ tri_colors, float *__restrict__ vbo,
+                                                   uint32_t *__restrict__ idx) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_tris) return;
+    float p[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t vi = indices[3 * size_t(t) + k];
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) p[k][ax] = vi < n_verts ? positions[3 * size_t(vi) + ax] : __builtin_nanf("");
+    }
+    const double ux = double(p[1][0]) - double(p[0][0]), uy = double(p[1][1]) - double(p[0][1]), uz = double(p[1][2]) - double(p[0][2]);
+    const double vx = double(p[2][0]) - double(p[0][0]), vy = double(p[2][1]) - double(p[0][1]), vz = double(p[2][2]) - double(p[0][2]);
+    double nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+    const double L = sqrt((nx * nx + ny * ny) + nz * nz);
+    if (L > 1e-8) { nx /= L; ny /= L; nz /= L; } else { nx = 0.0; ny = 1.0; nz = 0.0; }
+    const float r = tri_colors ? tri_colors[3 * size_t(t)] : 0.8f, g = tri_colors ? tri_colors[3 * size_t(t) + 1] : 0.8f,
+                b = tri_colors ? tri_colors[3 * size_t(t) + 2] : 0.8f;  // raster.js:145: default albedo
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float *o = vbo + (3 * size_t(t) + k) * 9;
+        o[0] = p[k][0]; o[1] = p[k][1]; o[2] = p[k][2];
+        o[3] = float(nx); o[4] = float(ny); o[5] = float(nz);
+        o[6] = r; o[7] = g; o[8] = b;
+        idx[3 * size_t(t) + k] = 3u * t + uint32_t(k);
+    }
+}
+
+// Copies the "sample the atlas" bit of every triangle's texel-coordinate row into its flag byte (all bits
+// cleared when triuv is null).
+__global__ __launch_bounds__(256) void k_uvflags(const uint4 *__restrict__ triuv, uint32_t n_tris, uint8_t *__restrict__ flat) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_tris) return;
+    const bool sample = triuv && (triuv[t].w & kUvSample) != 0u;
+    flat[t] = uint8_t((flat[t] & ~kFlagTextured) | (sample ? kFlagTextured : 0u));
+}
+
+__device__ __forceinline__ Vert<0> transform_position(const FrameParams &fp, float x, float y, float z) {
+    Vert<0> o;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        o.c[r] = ((fp.pv[0 * 4 + r] * x + fp.pv[1 * 4 + r] * y) + fp.pv[2 * 4 + r] * z) + fp.pv[3 * 4 + r];
+    return o;
+}
+
+// Range of bins a cell range touches.
+__device__ __forceinline__ void bin_range(const FrameParams &fp, int i0, int i1, int j0, int j1, int &bx0, int &bx1,
+                                          int &by0, int &by1) {
+    bx0 = i0 >> (6 + fp.bshift); bx1 = i1 >> (6 + fp.bshift);
+    by0 = (fp.rows - 1 - j1 - fp.ya) >> (kTileShiftH + fp.bshift); by1 = (fp.rows - 1 - j0 - fp.ya) >> (kTileShiftH + fp.bshift);
+}
+
+// One sub-triangle that survived setup: screen-space vertices and inclusive cell range.
+struct Candidate {
+    Screen sc;
+    int i0, i1, j0, j1;
+};
+
+// Setup of the triangle with vertex positions p[0..8]: transform, near clip, cull, cell range within
+// window rows [jlo, jhi].  c[s] / have[s] describe sub-triangle s; clipped tells whether the near
+// plane cut the triangle.
+__device__ __forceinline__ void triangle_setup(const FrameParams &fp, const float (&p)[9], int jlo, int jhi,
+                                               Candidate (&c)[2], bool (&have)[2], bool &clipped) {
+    const Vert<0> in0 = transform_position(fp, p[0], p[1], p[2]), in1 = transform_position(fp, p[3], p[4], p[5]),
+                  in2 = transform_position(fp, p[6], p[7], p[8]);
+    Vert<0> s0[3], s1[3];
+    const int ns = clip_near<0>(in0, in1, in2, s0, s1);
+    clipped = ns == 2 || (in0.c[2] + in0.c[3] < 0.0f) || (in1.c[2] + in1.c[3] < 0.0f) || (in2.c[2] + in2.c[3] < 0.0f);
+    have[0] = have[1] = false;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        if (s >= ns) continue;
+        const Vert<0> t0 = s ? s1[0] : s0[0], t1 = s ? s1[1] : s0[1], t2 = s ? s1[2] : s0[2];
+        if (!to_screen(t0.c, t1.c, t2.c, fp.hw, fp.hh, c[s].sc) || !front_facing(c[s].sc)) continue;
+        have[s] = cell_range(c[s].sc.X, c[s].sc.Y, c[s].sc.W, fp.cols, jlo, jhi, c[s].i0, c[s].i1, c[s].j0, c[s].j1);
+    }
+}
+
+__device__ __forceinline__ BinRec make_record(const Candidate &c, uint32_t id, uint32_t flags) {
+    BinRec r;
+#pragma unroll
+    for (int q = 0; q < 3; q++) { r.X[q] = c.sc.X[q]; r.Y[q] = c.sc.Y[q]; r.W[q] = c.sc.W[q]; r.Z[q] = c.sc.Z[q]; }
+    r.id = id;
+    r.i0 = uint16_t(c.i0); r.i1 = uint16_t(c.i1); r.j0 = uint16_t(c.j0); r.j1 = uint16_t(c.j1);
+    r.flags = flags;
+    return r;
+}
+
+// Workgroup g owns record slots [g * 2 * chunk, (g + 1) * 2 * chunk) and fills them densely, in
+// triangle order: a record's slot number ("loc") therefore grows with its id, and visibility keys
+// carry loc in place of the id - same tie-break, and the winner's record is found without a lookup.
+// surv: the cell ranges of the same slots, (i0 | i1 << 16, j0 | j1 << 16), all k_fill needs of a record.
+// One triangle per lane and pass; chunk is a multiple of the workgroup size (one pass up to about
+// four million triangles).
+__global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const float *__restrict__ tripos, size_t stride,
+                                                         const uint8_t *__restrict__ flat, BinRec *__restrict__ records,
+                                                         uint2 *__restrict__ surv, uint32_t *__restrict__ surv_count,
+                                                         uint32_t *__restrict__ dircount) {
+    __shared__ uint32_t hist[kMaxBins];
+    __shared__ uint32_t s_wave[kSetupThreads / 64];
+    const uint32_t tid = threadIdx.x;
+    const int nbins = fp.nbx * fp.nby;
+    const uint32_t t_begin = blockIdx.x * fp.chunk;
+    const uint32_t t_end = min(t_begin + fp.chunk, fp.n_tris);
+    for (int k = int(tid); k < nbins; k += kSetupThreads) hist[k] = 0;
+    __syncthreads();
+    const int jlo = fp.rows - fp.yb, jhi = fp.rows - 1 - fp.ya;
+    const uint32_t loc_base = blockIdx.x * 2u * fp.chunk;
+    uint32_t run = 0;  // slots handed out so far (identical in every lane)
+
+    for (uint32_t tb = t_begin; tb < t_end; tb += kSetupThreads) {
+        const uint32_t t = tb + tid;
+        const bool live = t < t_end;
+        Candidate c[2];
+        bool have[2] = {false, false}, clipped = false;
+        uint32_t flags = 0;
+        if (live) {
+            float p[9];
+#pragma unroll
+            for (int q = 0; q < 9; q++) p[q] = tripos[size_t(q) * stride + t];
+            flags = flat[t];  // kFlagFlat | kFlagTextured
+            triangle_setup(fp, p, jlo, jhi, c, have, clipped);
+            if (clipped) flags |= kFlagClipped;
+        }
+        uint32_t total;
+        uint32_t slot = run + block_exclusive_scan<kSetupThreads / 64>(uint32_t(have[0]) + uint32_t(have[1]), s_wave, total);
+        run += total;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            if (!have[s]) continue;
+            const uint32_t loc = loc_base + slot;
+            slot++;
+            records[loc] = make_record(c[s], 2u * t + uint32_t(s), flags);
+            surv[loc] = make_uint2(uint32_t(c[s].i0) | (uint32_t(c[s].i1) << 16), uint32_t(c[s].j0) | (uint32_t(c[s].j1) << 16));
+            int bx0, bx1, by0, by1;
+            bin_range(fp, c[s].i0, c[s].i1, c[s].j0, c[s].j1, bx0, bx1, by0, by1);
+            for (int by = by0; by <= by1; by++)
+                for (int bx = bx0; bx <= bx1; bx++) atomicAdd(&hist[by * fp.nbx + bx], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = int(tid); k < nbins; k += kSetupThreads) dircount[size_t(blockIdx.x) * nbins + k] = hist[k];
+    if (tid == 0) surv_count[blockIdx.x] = run;
+}
+
+// Column-wise exclusive prefix of the count table over the k_setup workgroups, in two levels.  The
+// table's rows are cut into 16 row blocks; workgroup (x, y) takes bins [64x, 64x + 64) of row block y
+// (its 16 wavefronts split the block's rows), rewrites table[g][b] as "entries of bin b that belong to
+// earlier workgroups of the same row block" and stores the block's total in blocksum[y][b].  k_fill
+// adds the totals of the earlier row blocks.  No global atomics, and the layout of every bin's entry
+// array is the same on every run.
+__global__ __launch_bounds__(1024) void k_binscan(FrameParams fp, uint32_t *__restrict__ table, uint32_t *__restrict__ blocksum) {
+    __shared__ uint32_t part[16][64];
+    const int nbins = fp.nbx * fp.nby;
+    const int lane = int(threadIdx.x & 63u), w = int(threadIdx.x >> 6);
+    const int b = int(blockIdx.x) * 64 + lane;
+    const uint32_t rows_per_block = (fp.n_groups + 15u) / 16u;
+    const uint32_t blk0 = min(uint32_t(blockIdx.y) * rows_per_block, fp.n_groups), blk1 = min(blk0 + rows_per_block, fp.n_groups);
+    const uint32_t rows_per_wave = (rows_per_block + 15u) / 16u;  // <= 16 (at most 4096 k_setup workgroups)
+    const uint32_t g0 = min(blk0 + uint32_t(w) * rows_per_wave, blk1), g1 = min(g0 + rows_per_wave, blk1);
+    uint32_t v[16], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        v[k] = (b < nbins && g0 + k < g1) ? table[size_t(g0 + k) * nbins + b] : 0u;
+        sum += v[k];
+    }
+    part[w][lane] = sum;
+    __syncthreads();
+    uint32_t run = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t x = part[k][lane];
+        if (k < w) run += x;
+        tot += x;
+    }
+    if (b < nbins) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (g0 + k < g1) table[size_t(g0 + k) * nbins + b] = run;
+            run += v[k];
+        }
+        if (w == 0) blocksum[size_t(blockIdx.y) * nbins + b] = tot;
+    }
+}
+
+// One workgroup: per bin, exclusive prefix of the 16 row-block totals and the bin's total; an
+// exclusive scan of the totals gives the start of each bin's entry array.  boff[y][b] = start of
+// bin b + entries of row blocks before y, so that k_fill only adds its own scanned table entry.
+__global__ __launch_bounds__(1024) void k_binoffsets(FrameParams fp, const uint32_t *__restrict__ blocksum,
+                                                     uint32_t *__restrict__ boff, BinState *__restrict__ state,
+                                                     uint32_t entries_cap) {
+    __shared__ uint32_t s_wave[16];
+    const int nbins = fp.nbx * fp.nby;
+    const uint32_t tid = threadIdx.x;
+    BinState &st = state[fp.set];
+    const int b0 = 2 * int(tid), b1 = b0 + 1;  // kMaxBins == 2 * 1024
+    uint32_t x0[16], x1[16], t0 = 0, t1 = 0;
+#pragma unroll
+    for (int y = 0; y < 16; y++) {
+        x0[y] = b0 < nbins ? blocksum[size_t(y) * nbins + b0] : 0u;
+        x1[y] = b1 < nbins ? blocksum[size_t(y) * nbins + b1] : 0u;
+        t0 += x0[y]; t1 += x1[y];
+    }
+    uint32_t n_entries;
+    const uint32_t s0 = block_exclusive_scan<16>(t0 + t1, s_wave, n_entries), s1 = s0 + t0;
+    const bool ok0 = s0 <= entries_cap && t0 <= entries_cap - s0, ok1 = s1 <= entries_cap && t1 <= entries_cap - s1;
+    uint32_t r0 = s0, r1 = s1;
+#pragma unroll
+    for (int y = 0; y < 16; y++) {
+        if (b0 < nbins) boff[size_t(y) * nbins + b0] = r0;
+        if (b1 < nbins) boff[size_t(y) * nbins + b1] = r1;
+        r0 += x0[y]; r1 += x1[y];
+    }
+    if (b0 < nbins) { st.start[b0] = s0; st.total[b0] = t0; }
+    if (b1 < nbins) { st.start[b1] = s1; st.total[b1] = t1; }
+    const int any_overflow = __syncthreads_or((b0 < nbins && !ok0 && t0) || (b1 < nbins && !ok1 && t1));
+    if (tid == 0) { st.n_entries = n_entries; st.overflow = any_overflow ? 1u : 0u; }
+}
+
+__global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const BinRec *__restrict__ records,
+                                                        const uint2 *__restrict__ surv,
+                                                        const uint32_t *__restrict__ surv_count,
+                                                        const uint32_t *__restrict__ dircount,
+                                                        const uint32_t *__restrict__ boff, const BinState *__restrict__ state,
+                                                        uint32_t *__restrict__ entries, uint32_t entries_cap,
+                                                        uint64_t *__restrict__ vis) {
+    __shared__ uint32_t base[kMaxBins], cnt[kMaxBins];
+    __shared__ uint8_t fits[kMaxBins];
+    const uint32_t tid = threadIdx.x;
+    const int nbins = fp.nbx * fp.nby;
+    const BinState &st = state[fp.set];
+    const uint32_t rows_per_block = (fp.n_groups + 15u) / 16u;
+    const uint32_t my_block = blockIdx.x / rows_per_block;
+    const uint32_t n = surv_count[blockIdx.x];
+    // where this workgroup's entries go inside each bin: start of the bin + entries of earlier row
+    // blocks (boff) + entries of earlier workgroups of its own row block (scanned table)
+    for (int b = int(tid); b < nbins; b += kSetupThreads) {
+        const uint32_t s0 = st.start[b], t0 = st.total[b];
+        base[b] = boff[size_t(my_block) * nbins + b] + dircount[size_t(blockIdx.x) * nbins + b];
+        cnt[b] = 0;
+        fits[b] = (s0 <= entries_cap && t0 <= entries_cap - s0) ? 1 : 0;
+    }
+    __syncthreads();
+    const uint32_t loc_base = blockIdx.x * 2u * fp.chunk;
+    for (uint32_t s = tid; s < n; s += kSetupThreads) {
+        const uint32_t loc = loc_base + s;  // record slot; also what the visibility keys carry
+        const uint2 sv = surv[loc];
+        const int i0 = int(sv.x & 0xFFFFu), i1 = int(sv.x >> 16), j0 = int(sv.y & 0xFFFFu), j1 = int(sv.y >> 16);
+        const int r0 = fp.rows - 1 - j1 - fp.ya, r1 = fp.rows - 1 - j0 - fp.ya;  // rows relative to the strip
+        const int tx0 = i0 >> 6, tx1 = i1 >> 6, ty0 = r0 >> kTileShiftH, ty1 = r1 >> kTileShiftH;
+        int bx0, bx1, by0, by1;
+        bin_range(fp, i0, i1, j0, j1, bx0, bx1, by0, by1);
+        bool direct = false;
+        for (int by = by0; by <= by1; by++)
+            for (int bx = bx0; bx <= bx1; bx++) {
+                const int b = by * fp.nbx + bx;
+                if (!fits[b]) { direct = true; continue; }
+                // tiles of this bin inside the record's tile range -> bit mask, bit = ay * side + ax
+                const int side = 1 << fp.bshift;
+                const int ax0 = max(tx0 - side * bx, 0), ax1 = min(tx1 - side * bx, side - 1);
+                const int ay0 = max(ty0 - side * by, 0), ay1 = min(ty1 - side * by, side - 1);
+                const uint32_t rowbits = ((1u << (ax1 + 1)) - 1u) & ~((1u << ax0) - 1u);
+                uint32_t m = 0;
+                for (int ay = ay0; ay <= ay1; ay++) m |= rowbits << (side * ay);
+                entries[size_t(base[b]) + atomicAdd(&cnt[b], 1u)] = loc | (m << kEntryMaskShift);
+            }
+        if (direct) {  // a bin it touches has no room: resolve through the global key buffer
+            Edges e;
+            edges_from_screen(records[loc], e);
+            for (int j = j0; j <= j1; j++) {
+                const size_t row = size_t(fp.rows - 1 - j) * fp.cols;
+                for (int i = i0; i <= i1; i++) {
+                    float f[3], zw;
+                    if (cover(e, i, j, f, zw)) vis_min(vis, row + i, make_key(zw, loc));
+                }
+            }
+        }
+    }
+}
+
+}  // namespace

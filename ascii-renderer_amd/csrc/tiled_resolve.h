@@ -1,0 +1,346 @@
+// tiled_resolve.h - tiled path, second half: per-tile LDS resolve and shading (k_tile)
+// Part of libascii_rast.so; included by ascii_rast.hip (one translation unit), not compiled on its own.
+#pragma once
+
+namespace {
+
+// Colour of cell (i, j) for a record the near plane cut.  The record holds the sub-triangle's screen
+// vertices, so only the varyings of its three vertices are missing: each is a mesh vertex or the point
+// I + (O - I) * (dI / (dI - dO)) on the edge from an inside vertex I to an outside vertex O, exactly as
+// clip_near builds them.  Which is which follows from the signs of d = z_c + w_c of the three mesh
+// vertices; the varyings are then rebuilt and interpolated one component at a time, which keeps this
+// rarely taken path from setting the register budget of the kernel that contains it.
+template <bool TEX>
+__device__ __forceinline__ void shade_clipped_record(const FrameParams &fp, const float *__restrict__ vbo,
+                                                     const uint32_t *__restrict__ idx, const uint4 *__restrict__ triuv,
+                                                     const uint32_t *__restrict__ atlas, const BinRec &rec, int i, int j,
+                                                     uint8_t (&px)[4]) {
+    const uint32_t t = rec.id >> 1, sub = rec.id & 1u;
+    const float *vp[3];
+    float d[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        vp[k] = vbo + size_t(idx[3 * size_t(t) + k]) * 9;
+        const float x = vp[k][0], y = vp[k][1], z = vp[k][2];
+        const float cz = ((fp.pv[2] * x + fp.pv[6] * y) + fp.pv[10] * z) + fp.pv[14];
+        const float cw = ((fp.pv[3] * x + fp.pv[7] * y) + fp.pv[11] * z) + fp.pv[15];
+        d[k] = cz + cw;
+    }
+    const bool in0 = d[0] >= 0.0f, in1 = d[1] >= 0.0f, in2 = d[2] >= 0.0f;
+    const int n_in = int(in0) + int(in1) + int(in2);
+    // A = the odd vertex out (the only inside one, or the only outside one), B and C follow it in winding order
+    const int a = (n_in == 1) ? (in0 ? 0 : (in1 ? 1 : 2)) : (!in0 ? 0 : (!in1 ? 1 : 2));
+    const int b = (a + 1) % 3, c = (a + 2) % 3;
+    // sub-triangle vertex m = mesh vertex I[m], or the point on the edge I[m] -> O[m] when O[m] >= 0
+    int I[3], O[3];
+    if (n_in == 1) { I[0] = a; O[0] = -1; I[1] = a; O[1] = b; I[2] = a; O[2] = c; }
+    else if (sub == 0u) { I[0] = b; O[0] = a; I[1] = b; O[1] = -1; I[2] = c; O[2] = -1; }
+    else { I[0] = b; O[0] = a; I[1] = c; O[1] = -1; I[2] = c; O[2] = a; }
+    float tt[3];
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+        const float dI = I[m] == 0 ? d[0] : (I[m] == 1 ? d[1] : d[2]);
+        const float dO = O[m] == 0 ? d[0] : (O[m] == 1 ? d[1] : d[2]);
+        tt[m] = dI / (dI - dO);
+    }
+    Edges e;
+    edges_from_screen(rec, e);
+    const double pxd = double(i) + 0.5, pyd = double(j) + 0.5;
+    float f[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) f[k] = float(e.a[k] * pxd + (e.b[k] * pyd + e.c[k]));
+    const float rS = 1.0f / ((f[0] + f[1]) + f[2]);
+    const float b0 = f[0] * rS, b1 = f[1] * rS, b2 = f[2] * rS;
+    // one varying with values o0, o1, o2 at the mesh vertices, at this cell
+    auto varying = [&](float o0, float o1, float o2) {
+        float sv[3];
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            const float vi = I[m] == 0 ? o0 : (I[m] == 1 ? o1 : o2);
+            const float vo = O[m] == 0 ? o0 : (O[m] == 1 ? o1 : o2);
+            sv[m] = O[m] < 0 ? vi : vi + (vo - vi) * tt[m];
+        }
+        return (b0 * sv[0] + b1 * sv[1]) + b2 * sv[2];
+    };
+    float v[9];
+    for (int q = 0; q < 9; q++) v[q] = varying(vp[0][q], vp[1][q], vp[2][q]);
+    if (TEX && (rec.flags & kFlagTextured)) {
+        const uint4 uv = triuv[t];
+        const float tu = varying(float(uv.x & 0xFFFFu), float(uv.y & 0xFFFFu), float(uv.z & 0xFFFFu));
+        const float tv = varying(float(uv.x >> 16), float(uv.y >> 16), float(uv.z >> 16));
+        if (apply_texture(fp, atlas, tu, tv, v + 6, px)) return;
+    }
+    shade(fp, v, px);
+}
+
+// Colour and depth of cell (i, j) from the winner's setup record; unclipped records take normal and
+// colour from the triangle's attribute row (one vertex's worth when the triangle is flat) and world
+// positions from the position planes (only when point lights are on); clipped ones are rebuilt by
+// shade_cell.
+template <bool TEX>
+__device__ __forceinline__ void shade_from_record(const FrameParams &fp, const float *__restrict__ vbo,
+                                                  const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
+                                                  const float *__restrict__ tripos, size_t stride,
+                                                  const uint4 *__restrict__ triuv, const uint32_t *__restrict__ atlas,
+                                                  const BinRec &rec, int i, int j, uint8_t (&px)[4], float &zw) {
+    if (rec.flags & kFlagClipped) { shade_clipped_record<TEX>(fp, vbo, idx, triuv, atlas, rec, i, j, px); return; }  // zw: the key's
+    const uint32_t t = rec.id >> 1;
+    const float4 *row = reinterpret_cast<const float4 *>(triattr) + size_t(t) * 6;
+    const int o1 = (rec.flags & kFlagFlat) ? 0 : 2, o2 = (rec.flags & kFlagFlat) ? 0 : 4;
+    const float4 a0 = row[0], a1 = row[o1], a2 = row[o2];
+    const float2 c0 = *reinterpret_cast<const float2 *>(row + 1), c1 = *reinterpret_cast<const float2 *>(row + o1 + 1),
+                 c2 = *reinterpret_cast<const float2 *>(row + o2 + 1);
+    Edges e;
+    edges_from_screen(rec, e);
+    float f[3];
+    cover(e, i, j, f, zw);
+    const float rS = 1.0f / ((f[0] + f[1]) + f[2]);
+    const float b0 = f[0] * rS, b1 = f[1] * rS, b2 = f[2] * rS;
+    float v[9];
+    v[3] = (b0 * a0.x + b1 * a1.x) + b2 * a2.x;
+    v[4] = (b0 * a0.y + b1 * a1.y) + b2 * a2.y;
+    v[5] = (b0 * a0.z + b1 * a1.z) + b2 * a2.z;
+    v[6] = (b0 * a0.w + b1 * a1.w) + b2 * a2.w;
+    v[7] = (b0 * c0.x + b1 * c1.x) + b2 * c2.x;
+    v[8] = (b0 * c0.y + b1 * c1.y) + b2 * c2.y;
+    if (fp.n_pl > 0) {
+        float p[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++) p[q] = tripos[size_t(q) * stride + t];
+#pragma unroll
+        for (int q = 0; q < 3; q++) v[q] = (b0 * p[q] + b1 * p[3 + q]) + b2 * p[6 + q];
+    } else {
+        v[0] = v[1] = v[2] = 0.0f;  // only the point-light loop reads the position
+    }
+    if (TEX && (rec.flags & kFlagTextured)) {
+        const uint4 uv = triuv[t];
+        const float tu = (b0 * float(uv.x & 0xFFFFu) + b1 * float(uv.y & 0xFFFFu)) + b2 * float(uv.z & 0xFFFFu);
+        const float tv = (b0 * float(uv.x >> 16) + b1 * float(uv.y >> 16)) + b2 * float(uv.z >> 16);
+        if (apply_texture(fp, atlas, tu, tv, v + 6, px)) return;
+    }
+    shade(fp, v, px);
+}
+
+// Scans rows [r0, r1] x columns [i0, i1] (at most 64 columns) of one record into the LDS key tile.
+// Most cells of a cell range lie outside the triangle, and lanes of a wavefront walk ranges of very
+// different sizes, so the scan is split in two: (1) per row, each edge function is evaluated in
+// binary32 and solved for the column where it crosses a conservative error band, which gives the
+// interval of columns that are not certainly outside - a run of bits in a 64-cell candidate mask;
+// (2) only those cells pay for the binary64 evaluation that decides coverage and feeds the depth.
+// The result is exactly that of testing every cell in binary64.
+// Band: with a32 = fl(a), r32 = fl(b py + c), |a32 px + r32 - E| <= 2^-24 (|a| px + |r|) (1 + eps); a cell
+// with E >= 0 therefore has a32 px + r32 >= -band / 32 for band = 2^-18 (|a32| px_max + |r32|), and lies
+// beyond the crossing column x of "a32 px + r32 = -band" by at least 0.8 band / |a32| >= 2^-19 |x|, far more
+// than the 2^-22 |x| the binary32 evaluation of x can be off.  Edges with a32 == 0 (or an overflowing
+// reciprocal) put no bound on the interval.
+__device__ __forceinline__ void raster_range(const FrameParams &fp, const Edges &ed, uint32_t key_low, int i0, int i1,
+                                             int r0, int r1, int tx0, int tr0, uint64_t *keys) {
+    constexpr float kBand = 1.0f / 262144.0f;  // 2^-18
+    const float a32[3] = {float(ed.a[0]), float(ed.a[1]), float(ed.a[2])};
+    // (hardware reciprocal: 1 ulp, inside the error budget above)
+    const float inv_a[3] = {__builtin_amdgcn_rcpf(a32[0]), __builtin_amdgcn_rcpf(a32[1]), __builtin_amdgcn_rcpf(a32[2])};
+    // coverage is E_k >= thr_k with thr_k = 0 on edges that own their boundary and the smallest positive
+    // binary64 otherwise (E_k > 0): the same decision as edge_inside with one comparison per edge
+    double thr[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        thr[k] = (ed.a[k] > 0.0 || (ed.a[k] == 0.0 && ed.b[k] > 0.0)) ? 0.0 : 4.9406564584124654e-324;
+    const float apx[3] = {fabsf(a32[0]) * float(i1 + 1), fabsf(a32[1]) * float(i1 + 1), fabsf(a32[2]) * float(i1 + 1)};
+    const int w = i1 - i0 + 1;
+    const int rows_per_chunk = max(1, 64 / w);
+    const float inv_w = 1.0f / float(w);
+    const float flo = float(i0), fhi = float(i1);
+    for (int rc = r0; rc <= r1; rc += rows_per_chunk) {
+        const int rc1 = min(rc + rows_per_chunk - 1, r1);
+        unsigned long long cand = 0ull;
+        for (int rr = rc; rr <= rc1; rr++) {
+            const double py = double(fp.rows - 1 - rr) + 0.5;
+            float lo = flo, hi = fhi;  // candidate columns, as cell indices
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float r32 = float(ed.b[k] * py + ed.c[k]);
+                const float band = kBand * (apx[k] + fabsf(r32));
+                const float x = (-band - r32) * inv_a[k] - 0.5f;  // crossing column as a cell index
+                lo = fmaxf(lo, a32[k] > 0.0f ? x : flo);
+                hi = fminf(hi, a32[k] < 0.0f ? x : fhi);
+            }
+            if (!(lo <= hi)) continue;
+            const int ilo = int(ceilf(lo)), ihi = int(floorf(hi));
+            const int n = ihi - ilo + 1;
+            if (n <= 0) continue;
+            const unsigned long long run = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+            cand |= run << ((rr - rc) * w + (ilo - i0));
+        }
+        uint32_t clo = uint32_t(cand), chi = uint32_t(cand >> 32);
+        while (clo | chi) {
+            int k;
+            if (clo) { k = __ffs(int(clo)) - 1; clo &= clo - 1u; }
+            else { k = 31 + __ffs(int(chi)); chi &= chi - 1u; }
+            const int dr = int((float(k) + 0.5f) * inv_w);  // k / w, exact for k < 64
+            const int rr = rc + dr, i = i0 + (k - dr * w);
+            const double px = double(i) + 0.5, py = double(fp.rows - 1 - rr) + 0.5;
+            const double E0 = ed.a[0] * px + (ed.b[0] * py + ed.c[0]);
+            const double E1 = ed.a[1] * px + (ed.b[1] * py + ed.c[1]);
+            const double E2 = ed.a[2] * px + (ed.b[2] * py + ed.c[2]);
+            const float f0 = float(E0), f1 = float(E1), f2 = float(E2);
+            const float den = (f0 * ed.W[0] + f1 * ed.W[1]) + f2 * ed.W[2];
+            const float num = (f0 * ed.Z[0] + f1 * ed.Z[1]) + f2 * ed.Z[2];
+            const float zw = (num / den) * 0.5f + 0.5f;
+            if ((E0 >= thr[0]) & (E1 >= thr[1]) & (E2 >= thr[2]) & (zw >= 0.0f) & (zw < 1.0f))
+                atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
+                          (unsigned long long)make_key(zw, key_low));
+        }
+    }
+}
+
+// TEX: the frame samples an atlas (texel coordinates and atlas are only read then).
+template <bool TEX>
+__global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__restrict__ vbo,
+                                              const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
+                                              const float *__restrict__ tripos, size_t stride,
+                                              const uint4 *__restrict__ triuv, const uint32_t *__restrict__ atlas,
+                                              const BinRec *__restrict__ records,
+                                              const uint32_t *__restrict__ entries, uint32_t entries_cap,
+                                              const BinState *__restrict__ state, uint64_t *__restrict__ vis,
+                                              uint8_t *__restrict__ rgba, float *__restrict__ depth,
+                                              uint8_t *__restrict__ ascii, uint8_t *__restrict__ ridx,
+                                              uint32_t *__restrict__ ids) {
+    __shared__ uint64_t keys[kTileCells];
+    __shared__ uint32_t list[kTileListMax];
+    __shared__ uint32_t big[kTileBigMax];
+    __shared__ uint16_t covered[kTileCells];
+    __shared__ uint32_t n_list, n_big, n_cov;
+    const uint32_t tid = threadIdx.x;
+    // Workgroups are handed to the eight XCDs round-robin and each XCD has its own L2: the tiles of one
+    // bin, which all read the bin's entry array, are given workgroup numbers that are equal modulo 8.
+    // Workgroup B = 8 * tiles_per_bin * g + 8 * k + x is tile k of bin 8 g + x.
+    const int side = 1 << fp.bshift, tiles_per_bin = side * side;
+    const int wg_group = int(blockIdx.x) / (8 * tiles_per_bin), wg_in = int(blockIdx.x) % (8 * tiles_per_bin);
+    const int bin = wg_group * 8 + (wg_in & 7), sub = wg_in >> 3;
+    if (bin >= fp.nbx * fp.nby) return;
+    const int tile_x = (bin % fp.nbx) * side + (sub & (side - 1)), tile_y = (bin / fp.nbx) * side + (sub >> fp.bshift);
+    if (tile_x >= fp.ntx || tile_y >= fp.nty) return;
+    const int tx0 = tile_x * kTileW, tr0 = fp.ya + tile_y * kTileH;                      // first column / output row
+    const int tx1 = min(tx0 + kTileW, fp.cols) - 1, tr1 = min(tr0 + kTileH, fp.yb) - 1;  // last column / row
+    const uint32_t bit = 1u << sub;
+    const BinState &st = state[fp.set];
+    for (int c = int(tid); c < kTileCells; c += 256) keys[c] = kBackgroundKey;
+    if (tid == 0) { n_list = 0; n_big = 0; n_cov = 0; }
+    const uint32_t e_begin = st.start[bin];
+    const uint32_t e_total = st.total[bin];
+    const bool stored = e_begin <= entries_cap && e_total <= entries_cap - e_begin;  // same test as k_fill
+    const uint32_t e_end = stored ? e_begin + e_total : e_begin;
+    __syncthreads();
+
+    // filter the bin's entries by this tile's mask bit into the LDS list; whenever the list could
+    // overflow on the next step (or at the end) rasterise what it holds
+    // (kFilterBatch entries per lane and step, all loads in flight together: the step is one memory latency)
+    for (uint32_t eb = e_begin;; eb += 256 * kFilterBatch) {
+        uint32_t ent[kFilterBatch];
+#pragma unroll
+        for (int q = 0; q < kFilterBatch; q++) {
+            const uint32_t e = eb + uint32_t(q) * 256u + tid;
+            ent[q] = e < e_end ? entries[e] : 0u;  // mask 0 never matches
+        }
+#pragma unroll
+        for (int q = 0; q < kFilterBatch; q++)
+            if ((ent[q] >> kEntryMaskShift) & bit) list[atomicAdd(&n_list, 1u)] = ent[q] & kEntryLocMask;
+        __syncthreads();
+        const uint32_t nl = n_list;
+        const bool last = eb + 256 * kFilterBatch >= e_end;
+        if (nl + 256 * kFilterBatch > uint32_t(kTileListMax) || last) {
+            // records with a small cell range inside the tile: one lane each; others -> sweep list
+            for (uint32_t r = tid; r < nl; r += 256) {
+                const uint32_t loc = list[r];
+                const BinRec rec = records[loc];
+                const int i0 = max(int(rec.i0), tx0), i1 = min(int(rec.i1), tx1);
+                const int r0 = max(fp.rows - 1 - int(rec.j1), tr0), r1 = min(fp.rows - 1 - int(rec.j0), tr1);
+                if ((i1 - i0 + 1) * (r1 - r0 + 1) > kTileSmallCells) {
+                    const uint32_t slot = atomicAdd(&n_big, 1u);
+                    if (slot < uint32_t(kTileBigMax)) { big[slot] = loc; continue; }
+                    // list full: this lane scans the range itself (slow but correct)
+                }
+                Edges ed;
+                edges_from_screen(rec, ed);
+                raster_range(fp, ed, loc, i0, i1, r0, r1, tx0, tr0, keys);
+            }
+            __syncthreads();
+            // sweep list: all lanes cover one record's cell range, 256 cells per step
+            const uint32_t nb = min(n_big, uint32_t(kTileBigMax));
+            for (uint32_t b = 0; b < nb; b++) {
+                const uint32_t loc = big[b];
+                const BinRec rec = records[loc];
+                const int i0 = max(int(rec.i0), tx0), i1 = min(int(rec.i1), tx1);
+                const int r0 = max(fp.rows - 1 - int(rec.j1), tr0), r1 = min(fp.rows - 1 - int(rec.j0), tr1);
+                const int w = i1 - i0 + 1, n = w * (r1 - r0 + 1);
+                Edges ed;
+                edges_from_screen(rec, ed);
+                for (int k = int(tid); k < n; k += 256) {
+                    const int dr = k / w, i = i0 + (k - dr * w), rr = r0 + dr;
+                    float f[3], zw;
+                    if (cover(ed, i, fp.rows - 1 - rr, f, zw))
+                        atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
+                                  (unsigned long long)make_key(zw, loc));
+                }
+            }
+            __syncthreads();
+            if (tid == 0) { n_list = 0; n_big = 0; }
+            __syncthreads();
+        }
+        if (last) break;
+    }
+
+    // sub-triangles k_fill could not store were resolved through the global key buffer
+    if (st.overflow != 0) {
+        for (int c = int(tid); c < kTileCells; c += 256) {
+            const int rr = tr0 + (c >> 6), i = tx0 + (c & 63);
+            if (i > tx1 || rr > tr1) continue;
+            const size_t cell = size_t(rr) * fp.cols + i;
+            const uint64_t g = vis[cell];
+            if (g != kBackgroundKey) {
+                vis[cell] = kBackgroundKey;
+                if (g < keys[c]) keys[c] = g;
+            }
+        }
+        __syncthreads();
+    }
+
+    // compact the covered cells so that shading runs on full wavefronts
+    for (int c = int(tid); c < kTileCells; c += 256)
+        if (keys[c] != kBackgroundKey) covered[atomicAdd(&n_cov, 1u)] = uint16_t(c);
+    __syncthreads();
+    const uint32_t nc = n_cov;
+    for (uint32_t k = tid; k < nc; k += 256) {
+        const int c = int(covered[k]);
+        const int rr = tr0 + (c >> 6), i = tx0 + (c & 63);
+        const BinRec rec = records[uint32_t(keys[c])];  // the key's low word is the winner's record slot
+        uint8_t px[4];
+        float zw = __uint_as_float(uint32_t(keys[c] >> 32));  // the depth the raster pass computed from this record
+        shade_from_record<TEX>(fp, vbo, idx, triattr, tripos, stride, triuv, atlas, rec, i, fp.rows - 1 - rr, px, zw);
+        if (fp.want_ids) ids[size_t(rr) * fp.cols + i] = rec.id;
+        keys[c] = (uint64_t(__float_as_uint(zw)) << 32) |
+                  (uint32_t(px[0]) | (uint32_t(px[1]) << 8) | (uint32_t(px[2]) << 16) | (uint32_t(px[3]) << 24));
+    }
+    __syncthreads();
+
+    // the tile's rows: 64 consecutive cells per row segment
+    for (int c = int(tid); c < kTileCells; c += 256) {
+        const int rr = tr0 + (c >> 6), i = tx0 + (c & 63);
+        if (i > tx1 || rr > tr1) continue;
+        const size_t cell = size_t(rr) * fp.cols + i;
+        const uint64_t k = keys[c];
+        const bool bg = k == kBackgroundKey;  // a shaded cell always has depth < 1.0 in the high word
+        const uint32_t col = bg ? 0xFF000000u : uint32_t(k);
+        reinterpret_cast<uint32_t *>(rgba)[cell] = col;
+        depth[cell] = bg ? 1.0f : __uint_as_float(uint32_t(k >> 32));
+        if (fp.want_ids && bg) ids[cell] = 0xFFFFFFFFu;
+        const int ri = ramp_index(int(col & 255u), int((col >> 8) & 255u), int((col >> 16) & 255u), fp.ramp_len);
+        if (fp.mode_on) ridx[cell] = uint8_t(ri);
+        else if (rr >= fp.row0 && rr < fp.row1) {
+            const uint32_t qa = col >> 24;  // 255 unless an atlas texel put an ASCII override there
+            ascii[cell] = (TEX && qa >= 2u && qa <= 254u) ? uint8_t(qa) : fp.ramp[ri];
+        }
+    }
+}
+
+}  // namespace

@@ -1,14 +1,17 @@
 """Writes build_variants/stamps.hip: the kernel source with wall-clock stamps at the phase boundaries of
 k_tile (diagnostic build only; never shipped).  Thread 0 of each tile records the 100 MHz clock after
 the barrier that ends each phase."""
-import os, re
+import os, re, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-s = open(os.path.join(root, "ascii-renderer_amd/csrc/ascii_rast.hip")).read()
+sys.path.insert(0, os.path.join(root, "scripts"))
+from flatten_source import flatten
+s = flatten()
 def rep(a, b):
     global s
     assert s.count(a) == 1, (s.count(a), a[:60])
     s = s.replace(a, b)
 rep("namespace {\n\nconstexpr uint64_t kBackgroundKey", "__device__ unsigned long long g_stamps[8192 * 8];\n#define STAMP(k) do { if (tid == 0) g_stamps[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)\nnamespace {\n\nconstexpr uint64_t kBackgroundKey")
+
 rep("    for (int c = int(tid); c < kTileCells; c += 256) keys[c] = kBackgroundKey;\n    if (tid == 0) { n_list = 0; n_big = 0; n_cov = 0; }", "    STAMP(0);\n    for (int c = int(tid); c < kTileCells; c += 256) keys[c] = kBackgroundKey;\n    if (tid == 0) { n_list = 0; n_big = 0; n_cov = 0; }")
 rep("        if (nl + 256 * kFilterBatch > uint32_t(kTileListMax) || last) {\n", "        if (nl + 256 * kFilterBatch > uint32_t(kTileListMax) || last) {\n            STAMP(1); if (tid == 0) g_stamps[blockIdx.x * 8 + 7] = nl;\n")
 rep("            __syncthreads();\n            // sweep list: all lanes cover one record's cell range, 256 cells per step", "            __syncthreads();\n            STAMP(2);\n            // sweep list: all lanes cover one record's cell range, 256 cells per step")
@@ -16,7 +19,7 @@ rep("            __syncthreads();\n            if (tid == 0) { n_list = 0; n_big
 rep("    __syncthreads();\n    const uint32_t nc = n_cov;", "    __syncthreads();\n    STAMP(4);\n    const uint32_t nc = n_cov;")
 rep("    __syncthreads();\n\n    // the tile's rows: 64 consecutive cells per row segment", "    __syncthreads();\n    STAMP(5);\n\n    // the tile's rows: 64 consecutive cells per row segment")
 # end of k_tile: find the closing of the output loop
-i = s.index("// ASCII stage without smoothing over an RGBA8 grid")
+i = s.index("// ascii_stage.h")
 j = s.rindex("}\n}\n", 0, i)
 s = s[:j] + "}\n    STAMP(6);\n}\n" + s[j + 4:]
 s += '\nextern "C" int ar_debug_stamps(unsigned long long *out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), size_t(n) * 8) == hipSuccess ? 0 : -1; }\n'
