@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E peak
+SCATTERED_LINES_G_PER_S = 36.0  # 128-byte lines per second (1e9) for scattered reads, scripts/micro/fetch_granularity.hip (profiles/r01f_fetch_granularity.txt)
 N_TRIS = 1_000_000
 COLS, ROWS = 1920, 1080
 
@@ -177,11 +178,13 @@ def main():
         dom = max(kern_serial, key=lambda k: kern_serial[k])
         dom_s = kern_serial[dom] * 1e-6
         achieved = per_launch_bytes.get(dom, 0) / dom_s / 1e9
-        traffic = None
+        traffic = requests = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
-                traffic = json.load(fh).get(dom)
+                tj = json.load(fh)
+            traffic = tj.get(dom)
+            requests = tj.get("_read_requests", {}).get(dom)
         line = {
             "metric": "frames/sec at 1920x1080 cell grid, 1M tris", "value": fps, "unit": "frames/s",
             "mtri_per_s": fps * args.tris / 1e6,
@@ -195,7 +198,12 @@ def main():
                        "frame_hbm_frac": ar.scenes.algorithmic_bytes(args.tris, args.cols, args.rows) * fps / 1e9 / HBM_PEAK_GBPS,
                        "queued_records": counters},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         # the kernel's reads are scattered lines: memory-side read requests per launch (PMC) over the live
+                         # duration, next to the scattered-line rate a microbenchmark reaches on this chip
+                         "read_requests": requests,
+                         "read_request_rate_G_per_s": (requests / dom_s / 1e9) if requests else None,
+                         "scattered_line_ceiling_G_per_s": SCATTERED_LINES_G_PER_S},
             "gather_verified": gather_ok,
             "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
             "kernels_avg_us_serial": {k: round(v, 2) for k, v in kern_serial.items()},
