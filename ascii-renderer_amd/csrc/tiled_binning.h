@@ -27,7 +27,7 @@ namespace {
 //             tiles the cell range touches) per (survivor, bin), written into that workgroup's slice.
 //   k_tile    one workgroup per tile: filters its bin's entries by mask bit into an LDS work list,
 //             rasterises those records into a 2048-entry LDS key tile with LDS atomic min (small
-//             cell ranges: one lane per record; large ones: all lanes sweep the range), then shades
+//             cell ranges: one lane per record; large ones: staged in LDS, one wavefront sweeps each), then shades
 //             the covered cells and writes the tile's RGBA / depth / ramp-index rows.  Visibility
 //             keys never touch HBM.
 // If the entry pool cannot hold a bin, the sub-triangles touching that bin are rasterised straight
@@ -44,6 +44,7 @@ constexpr int kMaxBins = 2048;        // >= kMaxTiles / 4 for any tile-grid shap
 constexpr int kSetupThreads = 256;    // k_setup / k_fill workgroup size
 constexpr uint32_t kMaxGroups = 1024;  // k_setup workgroups (rows of the count table)
 constexpr int kTileBigMax = 512;      // per-tile list of records swept cooperatively
+constexpr int kTileStage = 64;        // of which so many are staged in LDS at a time (64 B each, in the cell list's 4 KB)
 constexpr int kTileSmallCells = 64;   // cell-range area (inside the tile) one lane scans itself
 constexpr int kTileListMax = 2048;    // ids staged in LDS between the filter and the raster step
 constexpr int kEntryMaskShift = 28;   // a bin entry is (record slot) | (mask of the bin's 2x2 tiles) << 28

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
     __shared__ uint64_t keys[kTileCells];
     __shared__ uint32_t list[kTileListMax];
     __shared__ uint32_t big[kTileBigMax];
-    __shared__ uint16_t covered[kTileCells];
+    __shared__ __align__(16) uint16_t covered[kTileCells];  // covered cells for the shading step; before that, staging for swept records
     __shared__ uint32_t n_list, n_big, n_cov;
     const uint32_t tid = threadIdx.x;
     // Workgroups are handed to the eight XCDs round-robin and each XCD has its own L2: the tiles of one
@@ -265,25 +265,33 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
                 raster_range(fp, ed, loc, i0, i1, r0, r1, tx0, tr0, keys);
             }
             __syncthreads();
-            // sweep list: all lanes cover one record's cell range, 256 cells per step
+            // sweep list: the records are brought into LDS 64 at a time (one fetch latency per batch instead of
+            // one per record), then every wavefront sweeps a record of its own, 64 cells per step
             const uint32_t nb = min(n_big, uint32_t(kTileBigMax));
-            for (uint32_t b = 0; b < nb; b++) {
-                const uint32_t loc = big[b];
-                const BinRec rec = records[loc];
-                const int i0 = max(int(rec.i0), tx0), i1 = min(int(rec.i1), tx1);
-                const int r0 = max(fp.rows - 1 - int(rec.j1), tr0), r1 = min(fp.rows - 1 - int(rec.j0), tr1);
-                const int w = i1 - i0 + 1, n = w * (r1 - r0 + 1);
-                Edges ed;
-                edges_from_screen(rec, ed);
-                for (int k = int(tid); k < n; k += 256) {
-                    const int dr = k / w, i = i0 + (k - dr * w), rr = r0 + dr;
-                    float f[3], zw;
-                    if (cover(ed, i, fp.rows - 1 - rr, f, zw))
-                        atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
-                                  (unsigned long long)make_key(zw, loc));
+            BinRec *stage = reinterpret_cast<BinRec *>(covered);  // (the cell list is not in use before the raster step ends)
+            for (uint32_t b0 = 0; b0 < nb; b0 += kTileStage) {
+                const uint32_t ns = min(uint32_t(kTileStage), nb - b0);
+                if (tid < ns) stage[tid] = records[big[b0 + tid]];
+                __syncthreads();
+                for (uint32_t q = tid >> 6; q < ns; q += 4) {
+                    const BinRec &rec = stage[q];
+                    const uint32_t loc = big[b0 + q];
+                    const int i0 = max(int(rec.i0), tx0), i1 = min(int(rec.i1), tx1);
+                    const int r0 = max(fp.rows - 1 - int(rec.j1), tr0), r1 = min(fp.rows - 1 - int(rec.j0), tr1);
+                    const int w = i1 - i0 + 1, n = w * (r1 - r0 + 1);
+                    Edges ed;
+                    edges_from_screen(rec, ed);
+                    for (int k = int(tid & 63u); k < n; k += 64) {
+                        const int dr = k / w, i = i0 + (k - dr * w), rr = r0 + dr;
+                        float f[3], zw;
+                        if (cover(ed, i, fp.rows - 1 - rr, f, zw))
+                            atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
+                                      (unsigned long long)make_key(zw, loc));
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
+            __syncthreads();  // (every lane has read n_big by now)
             if (tid == 0) { n_list = 0; n_big = 0; }
             __syncthreads();
         }

@@ -4,18 +4,22 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ar = importlib.import_module("ascii-renderer_amd")
 ar.binding.LIB_PATH = os.environ["AR_LIB"]
-sc = ar.scenes.random_scene(1000000, 1920, 1080)
+which = os.environ.get("AR_SCENE", "c3")     # c3 (default) | ico (C2) | cube (C1)
+sc = {"c3": lambda: ar.scenes.random_scene(1000000, 1920, 1080), "ico": ar.scenes.icosphere_scene, "cube": ar.scenes.cube_scene}[which]()
 R = ar.Renderer(0)
 R.set_option("overlap", 0)
 ar.scenes.upload(R, sc)
-for _ in range(5): R.render_async(1920, 1080)
+for _ in range(5): R.render_async(sc["cols"], sc["rows"])
 R.sync()
 L = ar.load_library()
-n = 1020 * 8
+ntx, nty = (sc["cols"] + 63) // 64, (sc["rows"] + 31) // 32
+n_wg = ((((ntx + 1) // 2) * ((nty + 1) // 2) + 7) // 8 * 8) * 4        # k_tile's grid: bins rounded up to 8, four tiles each
+n = n_wg * 8
 out = np.zeros(n, dtype=np.uint64)
 L.ar_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert L.ar_debug_stamps(out.ctypes.data_as(ctypes.c_void_p), n) == 0
-st = out.reshape(1020, 8).astype(np.int64)
+st = out.reshape(n_wg, 8).astype(np.int64)
+st = st[st[:, 6] > 0]                       # workgroups beyond the tile grid return before the first stamp
 t0 = st[:, 0].min()
 names = ["filter", "raster small", "raster big", "compact", "shade", "output"]
 for k, nm in enumerate(names):
