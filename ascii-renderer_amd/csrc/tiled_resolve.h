@@ -250,9 +250,13 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
         const bool last = eb + 256 * kFilterBatch >= e_end;
         if (nl + 256 * kFilterBatch > uint32_t(kTileListMax) || last) {
             // records with a small cell range inside the tile: one lane each; others -> sweep list
+            // (a lane's next record is fetched while it works on the current one)
+            BinRec ahead;
+            if (tid < nl) ahead = records[list[tid]];
             for (uint32_t r = tid; r < nl; r += 256) {
                 const uint32_t loc = list[r];
-                const BinRec rec = records[loc];
+                const BinRec rec = ahead;
+                if (r + 256 < nl) ahead = records[list[r + 256]];
                 const int i0 = max(int(rec.i0), tx0), i1 = min(int(rec.i1), tx1);
                 const int r0 = max(fp.rows - 1 - int(rec.j1), tr0), r1 = min(fp.rows - 1 - int(rec.j0), tr1);
                 if ((i1 - i0 + 1) * (r1 - r0 + 1) > kTileSmallCells) {
