@@ -1,7 +1,7 @@
 // ascii_rast.hip - MI355X (gfx950) 3D -> ASCII rasterizer: HIP kernels and the C ABI around them.
 //
 // Two resolve paths produce identical frames (nothing leaves HBM between their stages):
-//   tiled (default)   k_setup -> k_binscan -> k_binoffsets -> k_fill -> k_tile -> k_ascii_plane
+//   tiled (default)   k_setup -> k_binscan -> k_fill -> k_tile -> k_ascii_plane
 //                     triangles are set up once, binned to screen bins and resolved per 64x32-cell
 //                     tile in LDS; described in front of k_tristream.
 //   direct            k_raster -> k_raster_medium -> k_raster_large -> k_shade -> k_ascii_plane

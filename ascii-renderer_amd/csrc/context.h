@@ -303,7 +303,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
             if (rc) return rc;
             for (int k = 0; k < kSets; k++) { (void)hipFree(ctx->d_dircount[k]); ctx->d_dircount[k] = nullptr; }
             ctx->dircount_cap = 0;
-            for (int k = 0; k < kSets; k++) AR_HIP(ctx, hipMalloc(&ctx->d_dircount[k], (want_dir + 32 * size_t(kMaxBins)) * sizeof(uint32_t)));
+            for (int k = 0; k < kSets; k++) AR_HIP(ctx, hipMalloc(&ctx->d_dircount[k], (want_dir + 16 * size_t(kMaxBins)) * sizeof(uint32_t)));
             ctx->dircount_cap = want_dir;
         }
     }
@@ -325,7 +325,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
     }
     if (tiled) {
         uint32_t *dircount = ctx->d_dircount[set];
-        uint32_t *blocksum = dircount + ctx->dircount_cap, *boff = blocksum + 16 * size_t(kMaxBins);
+        uint32_t *blocksum = dircount + ctx->dircount_cap;
         {
             Stamper s(ctx, K_SETUP, fs);
             k_setup<<<fp.n_groups, kSetupThreads, 0, fs>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_flat, ctx->d_records[set],
@@ -336,12 +336,8 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
             k_binscan<<<dim3(unsigned((nbins + 63) / 64), 16), 1024, 0, fs>>>(fp, dircount, blocksum);
         }
         {
-            Stamper s(ctx, K_BINOFF, fs);
-            k_binoffsets<<<1, 1024, 0, fs>>>(fp, blocksum, boff, ctx->d_state, ctx->pool_cap);
-        }
-        {
             Stamper s(ctx, K_FILL, fs);
-            k_fill<<<fp.n_groups, kSetupThreads, 0, fs>>>(fp, ctx->d_records[set], ctx->d_surv[set], ctx->d_surv_count[set], dircount, boff,
+            k_fill<<<fp.n_groups, kSetupThreads, 0, fs>>>(fp, ctx->d_records[set], ctx->d_surv[set], ctx->d_surv_count[set], dircount, blocksum,
                                                         ctx->d_state, ctx->d_entries[set], ctx->pool_cap, ctx->d_vis[set]);
         }
         {

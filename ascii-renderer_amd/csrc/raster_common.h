@@ -10,10 +10,10 @@ constexpr int kMediumMaxCells = 4096;   // above this a record goes to the per-c
 constexpr uint32_t kMediumCapacity = 1u << 18;
 constexpr uint32_t kLargeCapacity = 1u << 14;
 
-enum KernelSlot { K_CLEAR = 0, K_RASTER, K_MEDIUM, K_LARGE, K_SHADE, K_ASCII, K_SETUP, K_BINSCAN, K_BINOFF, K_FILL, K_TILE, K_PRESENT, K_RAYTRACE };
+enum KernelSlot { K_CLEAR = 0, K_RASTER, K_MEDIUM, K_LARGE, K_SHADE, K_ASCII, K_SETUP, K_BINSCAN, K_FILL, K_TILE, K_PRESENT, K_RAYTRACE };
 const char *const kKernelNames[AR_N_KERNELS] = {"k_clear",  "k_raster", "k_raster_medium", "k_raster_large",
                                                 "k_shade", "k_ascii",  "k_setup",         "k_binscan",
-                                                "k_binoffsets", "k_fill", "k_tile", "k_present",
+                                                "k_fill", "k_tile", "k_present",
                                                 "k_raytrace"};
 
 // Everything a frame's kernels need besides the big buffers; passed by value as a kernel argument.

@@ -21,9 +21,8 @@ namespace {
 //   k_binscan column-wise exclusive prefix of the count table over the k_setup workgroups (in
 //             place, two levels) and per-row-block bin totals: every (workgroup, bin) pair gets a
 //             fixed slice of the bin's entry array without a single global atomic.
-//   k_binoffsets  bin totals, start of each bin's entry array (exclusive scan), row-block offsets,
-//             overflow flag.
-//   k_fill    every k_setup workgroup's survivors become one entry (record slot, mask of the bin's
+//   k_fill    bin totals -> start of every bin's entry array (each workgroup scans them for itself), then
+//             every k_setup workgroup's survivors become one entry (record slot, mask of the bin's
 //             tiles the cell range touches) per (survivor, bin), written into that workgroup's slice.
 //   k_tile    one workgroup per tile: filters its bin's entries by mask bit into an LDS work list,
 //             rasterises those records into a 2048-entry LDS key tile with LDS atomic min (small
@@ -31,7 +30,7 @@ namespace {
 //             the covered cells and writes the tile's RGBA / depth / ramp-index rows.  Visibility
 //             keys never touch HBM.
 // If the entry pool cannot hold a bin, the sub-triangles touching that bin are rasterised straight
-// into a global key buffer by k_fill, k_binoffsets raises the frame's overflow flag and k_tile merges
+// into a global key buffer by k_fill, which also raises the frame's overflow flag, and k_tile merges
 // that buffer in.
 // Everything a frame writes exists kSets times, so that consecutive frames can overlap: see
 // enqueue_frame.
@@ -65,7 +64,7 @@ static_assert(sizeof(BinRec) == 64, "bin records are four 16-byte loads");
 // Per-frame binning state; one block per buffer set.
 struct BinState {
     uint32_t total[kMaxBins];
-    uint32_t start[kMaxBins];   // exclusive scan of total (k_binoffsets)
+    uint32_t start[kMaxBins];   // exclusive scan of total (k_fill)
     uint32_t overflow;          // some bin did not fit the entry pool
     uint32_t n_entries;         // sum of total
     uint32_t pad[2];
@@ -324,63 +323,65 @@ __global__ __launch_bounds__(1024) void k_binscan(FrameParams fp, uint32_t *__re
     }
 }
 
-// One workgroup: per bin, exclusive prefix of the 16 row-block totals and the bin's total; an
-// exclusive scan of the totals gives the start of each bin's entry array.  boff[y][b] = start of
-// bin b + entries of row blocks before y, so that k_fill only adds its own scanned table entry.
-__global__ __launch_bounds__(1024) void k_binoffsets(FrameParams fp, const uint32_t *__restrict__ blocksum,
-                                                     uint32_t *__restrict__ boff, BinState *__restrict__ state,
-                                                     uint32_t entries_cap) {
-    __shared__ uint32_t s_wave[16];
-    const int nbins = fp.nbx * fp.nby;
-    const uint32_t tid = threadIdx.x;
-    BinState &st = state[fp.set];
-    const int b0 = 2 * int(tid), b1 = b0 + 1;  // kMaxBins == 2 * 1024
-    uint32_t x0[16], x1[16], t0 = 0, t1 = 0;
-#pragma unroll
-    for (int y = 0; y < 16; y++) {
-        x0[y] = b0 < nbins ? blocksum[size_t(y) * nbins + b0] : 0u;
-        x1[y] = b1 < nbins ? blocksum[size_t(y) * nbins + b1] : 0u;
-        t0 += x0[y]; t1 += x1[y];
-    }
-    uint32_t n_entries;
-    const uint32_t s0 = block_exclusive_scan<16>(t0 + t1, s_wave, n_entries), s1 = s0 + t0;
-    const bool ok0 = s0 <= entries_cap && t0 <= entries_cap - s0, ok1 = s1 <= entries_cap && t1 <= entries_cap - s1;
-    uint32_t r0 = s0, r1 = s1;
-#pragma unroll
-    for (int y = 0; y < 16; y++) {
-        if (b0 < nbins) boff[size_t(y) * nbins + b0] = r0;
-        if (b1 < nbins) boff[size_t(y) * nbins + b1] = r1;
-        r0 += x0[y]; r1 += x1[y];
-    }
-    if (b0 < nbins) { st.start[b0] = s0; st.total[b0] = t0; }
-    if (b1 < nbins) { st.start[b1] = s1; st.total[b1] = t1; }
-    const int any_overflow = __syncthreads_or((b0 < nbins && !ok0 && t0) || (b1 < nbins && !ok1 && t1));
-    if (tid == 0) { st.n_entries = n_entries; st.overflow = any_overflow ? 1u : 0u; }
-}
-
+// Every workgroup first works out, from the 16 row-block totals per bin (k_binscan's blocksum), where each bin's
+// entry array starts - total per bin, exclusive scan over the bins - and where its own entries go inside it:
+// start of the bin + entries of earlier row blocks + entries of earlier workgroups of its own row block (the
+// scanned table).  The totals are 16 x bins words read from L2 per workgroup; recomputing them here saves the frame
+// a kernel whose only job was this scan.  Workgroup 0 also publishes start / total / overflow for k_tile.
 __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const BinRec *__restrict__ records,
                                                         const uint2 *__restrict__ surv,
                                                         const uint32_t *__restrict__ surv_count,
                                                         const uint32_t *__restrict__ dircount,
-                                                        const uint32_t *__restrict__ boff, const BinState *__restrict__ state,
+                                                        const uint32_t *__restrict__ blocksum, BinState *__restrict__ state,
                                                         uint32_t *__restrict__ entries, uint32_t entries_cap,
                                                         uint64_t *__restrict__ vis) {
-    __shared__ uint32_t base[kMaxBins], cnt[kMaxBins];
+    __shared__ uint32_t base[kMaxBins], cnt[kMaxBins];  // cnt holds the bin totals until the offsets are done
     __shared__ uint8_t fits[kMaxBins];
+    __shared__ uint32_t s_wave[kSetupThreads / 64];
     const uint32_t tid = threadIdx.x;
     const int nbins = fp.nbx * fp.nby;
-    const BinState &st = state[fp.set];
+    BinState &st = state[fp.set];
     const uint32_t rows_per_block = (fp.n_groups + 15u) / 16u;
     const uint32_t my_block = blockIdx.x / rows_per_block;
     const uint32_t n = surv_count[blockIdx.x];
-    // where this workgroup's entries go inside each bin: start of the bin + entries of earlier row
-    // blocks (boff) + entries of earlier workgroups of its own row block (scanned table)
     for (int b = int(tid); b < nbins; b += kSetupThreads) {
-        const uint32_t s0 = st.start[b], t0 = st.total[b];
-        base[b] = boff[size_t(my_block) * nbins + b] + dircount[size_t(blockIdx.x) * nbins + b];
-        cnt[b] = 0;
-        fits[b] = (s0 <= entries_cap && t0 <= entries_cap - s0) ? 1 : 0;
+        uint32_t total = 0, before = 0;
+#pragma unroll
+        for (uint32_t y = 0; y < 16; y++) {
+            const uint32_t x = blocksum[size_t(y) * nbins + b];
+            total += x;
+            before += y < my_block ? x : 0u;
+        }
+        cnt[b] = total;
+        base[b] = before + dircount[size_t(blockIdx.x) * nbins + b];
     }
+    __syncthreads();
+    // exclusive scan of the totals over the bins: each lane takes a run of consecutive bins
+    constexpr int kRun = kMaxBins / kSetupThreads;
+    uint32_t run_total = 0;
+#pragma unroll
+    for (int q = 0; q < kRun; q++) {
+        const int b = int(tid) * kRun + q;
+        run_total += b < nbins ? cnt[b] : 0u;
+    }
+    uint32_t n_entries;
+    uint32_t start = block_exclusive_scan<kSetupThreads / 64>(run_total, s_wave, n_entries);
+    bool overflow = false;
+#pragma unroll
+    for (int q = 0; q < kRun; q++) {
+        const int b = int(tid) * kRun + q;
+        if (b >= nbins) break;
+        const uint32_t total = cnt[b];
+        const bool ok = start <= entries_cap && total <= entries_cap - start;
+        base[b] += start;
+        fits[b] = ok ? 1 : 0;
+        overflow = overflow || (!ok && total != 0u);
+        if (blockIdx.x == 0) { st.start[b] = start; st.total[b] = total; }
+        start += total;
+    }
+    const int any_overflow = __syncthreads_or(overflow);
+    if (blockIdx.x == 0 && tid == 0) { st.n_entries = n_entries; st.overflow = any_overflow ? 1u : 0u; }
+    for (int b = int(tid); b < nbins; b += kSetupThreads) cnt[b] = 0;
     __syncthreads();
     const uint32_t loc_base = blockIdx.x * 2u * fp.chunk;
     for (uint32_t s = tid; s < n; s += kSetupThreads) {

@@ -165,7 +165,7 @@ def main():
             "k_tile": cells * 9,
             "k_ascii": cells * 2,                        # ramp index in, ASCII code out
             "k_fill": counters["bin_records"] * 4,       # one 4-byte entry per (sub-triangle, bin)
-            "k_binscan": 0, "k_binoffsets": 0,           # bookkeeping: no algorithmic traffic of their own
+            "k_binscan": 0,                                # bookkeeping: no algorithmic traffic of its own
             # direct path: reference layout, 3 x 36 B vertices + 12 B indices per triangle
             "k_raster": args.tris * 120,
             "k_shade": cells * 9,                        # RGBA8 + depth f32 + ASCII per cell

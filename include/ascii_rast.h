@@ -222,7 +222,7 @@ int ar_rt_render_async(ar_ctx *ctx, int cols, int rows, const float cam_pos[3], 
 /* Per-kernel timing with HIP events on the context's stream.  While on, every launch is bracketed by
  * events; ar_kernel_stats drains them (blocking) and reports, per kernel slot, the number of launches
  * and the summed duration in milliseconds since the last call.  names receives static strings. */
-#define AR_N_KERNELS 13
+#define AR_N_KERNELS 12
 int ar_set_profiling(ar_ctx *ctx, int on);
 int ar_kernel_stats(ar_ctx *ctx, const char *names[AR_N_KERNELS], uint32_t launches[AR_N_KERNELS], float total_ms[AR_N_KERNELS]);
 
