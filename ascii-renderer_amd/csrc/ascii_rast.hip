@@ -2,7 +2,7 @@
 //
 // Two resolve paths produce identical frames (nothing leaves HBM between their stages):
 //   tiled (default)   k_setup -> k_binscan -> k_fill -> k_tile -> k_ascii_plane
-//                     triangles are set up once, binned to screen bins and resolved per 64x32-cell
+//                     triangles are culled and binned to screen bins, then resolved per 64x32-cell
 //                     tile in LDS; described in front of k_tristream.
 //   direct            k_raster -> k_raster_medium -> k_raster_large -> k_shade -> k_ascii_plane
 //                     k_raster: one lane per triangle (vertex transform, near clip, edge setup, cull,
@@ -13,8 +13,7 @@
 //                     RGBA8, depth, ramp quantisation; ASCII written here when smoothing is off).
 //                     Used for grids beyond the tiled path's tile budget, or on request.
 // Visibility is resolved with one 64-bit key per cell, (depth bits << 32) | order, reduced with unsigned
-// min: smaller depth wins, equal depth goes to the earlier triangle (order = 2*triangle + sub on the
-// direct path, the record slot - handed out in triangle order - on the tiled path), and the result
+// min: smaller depth wins, equal depth goes to the earlier triangle (order = 2*triangle + sub), and the result
 // does not depend on the order in which lanes, waves or kernels reach a cell.
 //
 // Arithmetic follows a fixed contract (binary32 transforms and shading, binary64 edge functions,
@@ -90,11 +89,11 @@ void ar_destroy(ar_ctx *ctx) {
     (void)hipFree(ctx->d_medium); (void)hipFree(ctx->d_large); (void)hipFree(ctx->d_counters);
     (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii); (void)hipFree(ctx->d_q_colors);
     (void)hipFree(ctx->d_p_atlas); (void)hipFree(ctx->d_p_cov); (void)hipFree(ctx->d_p_image);
-    (void)hipFree(ctx->d_state); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr); (void)hipFree(ctx->d_flat);
+    (void)hipFree(ctx->d_state); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr); (void)hipFree(ctx->d_tri);
     (void)hipFree(ctx->d_triuv); (void)hipFree(ctx->d_atlas); (void)hipFree(ctx->d_rt);
     for (int k = 0; k < kSets; k++) {
-        (void)hipFree(ctx->d_entries[k]); (void)hipFree(ctx->d_surv[k]); (void)hipFree(ctx->d_surv_count[k]);
-        (void)hipFree(ctx->d_dircount[k]); (void)hipFree(ctx->d_records[k]);
+        (void)hipFree(ctx->d_entries[k]); (void)hipFree(ctx->d_surv[k]); (void)hipFree(ctx->d_sid[k]); (void)hipFree(ctx->d_surv_count[k]);
+        (void)hipFree(ctx->d_dircount[k]);
     }
     for (int k = 0; k <= kSets; k++)
         if (ctx->ev_out[k]) (void)hipEventDestroy(ctx->ev_out[k]);
@@ -177,7 +176,7 @@ int ar_set_mesh_uv(ar_ctx *ctx, const uint16_t *uv8, uint32_t n_tris) {
         AR_HIP(ctx, hipMalloc(&ctx->d_triuv, size_t(n_tris) * sizeof(uint4)));
         AR_HIP(ctx, hipMemcpy(ctx->d_triuv, uv8, size_t(n_tris) * sizeof(uint4), hipMemcpyHostToDevice));
     }
-    k_uvflags<<<(ctx->n_tris + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_triuv, ctx->n_tris, ctx->d_flat);
+    k_uvflags<<<(ctx->n_tris + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_triuv, ctx->n_tris, ctx->d_tri);
     AR_HIP(ctx, hipGetLastError());
     AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;

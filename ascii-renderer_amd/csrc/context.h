@@ -47,8 +47,7 @@ struct ar_ctx {
     size_t tripos_stride = 0;
     float *d_triattr = nullptr;      // n_tris x 24 floats: the three vertices' normals and colours
     // everything the binning kernels write, per buffer set
-    BinRec *d_records[kSets] = {};  // 2 x n_tris setup record slots, filled densely per k_setup workgroup
-    uint8_t *d_flat = nullptr;       // n_tris flag bytes: kFlagFlat | kFlagTextured
+    TriStatic *d_tri = nullptr;      // n_tris 64-byte triangle records: positions, flat normal and colour, flags
     void *d_rt = nullptr;            // ray backend: the scene arrays of ar_rt_set_scene in one allocation
     RtScene rt_scene = {};           // counts and device pointers into d_rt
     bool rt_has_scene = false;
@@ -56,10 +55,11 @@ struct ar_ctx {
     uint32_t *d_atlas = nullptr;     // atlas texels (ar_set_texture), else null
     int atlas_w = 0, atlas_h = 0;
     uint2 *d_surv[kSets] = {};  // per k_setup workgroup: cell ranges of its surviving sub-triangles
+    uint32_t *d_sid[kSets] = {};  // ... and their ids, 2*triangle + sub
     uint32_t *d_surv_count[kSets] = {};
     uint32_t *d_dircount[kSets] = {};  // per k_setup workgroup: entries per bin (+ scan scratch)
     size_t group_cap = 0, dircount_cap = 0;
-    uint32_t *d_entries[kSets] = {};  // (record slot, tile mask) entries grouped by bin
+    uint32_t *d_entries[kSets] = {};  // (2*triangle + sub, tile mask) entries grouped by bin
     uint32_t pool_cap = 0;
     BinState *d_state = nullptr;     // kSets blocks
     uint32_t frame = 0;              // tiled frames enqueued so far
@@ -182,24 +182,22 @@ int drop_mesh(ar_ctx *ctx) {
     int rc = sync_streams(ctx);
     if (rc) return rc;
     (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr);
-    (void)hipFree(ctx->d_flat); (void)hipFree(ctx->d_triuv);
-    for (int k = 0; k < kSets; k++) { (void)hipFree(ctx->d_records[k]); ctx->d_records[k] = nullptr; }
+    (void)hipFree(ctx->d_tri); (void)hipFree(ctx->d_triuv);
     ctx->d_vbo = nullptr; ctx->d_idx = nullptr; ctx->d_tripos = nullptr; ctx->d_triattr = nullptr;
-    ctx->d_flat = nullptr; ctx->d_triuv = nullptr;  // texel coordinates belong to the mesh they were given for
+    ctx->d_tri = nullptr; ctx->d_triuv = nullptr;  // texel coordinates belong to the mesh they were given for
     ctx->n_verts = 0; ctx->n_tris = 0;
     return 0;
 }
 
-// d_vbo / d_idx hold the new mesh: derive the streams of the tiled path (positions, attribute rows, flag
-// bytes) and allocate its record slots.
+// d_vbo / d_idx hold the new mesh: derive the streams of the tiled path (position planes, attribute rows,
+// triangle records).
 int finish_mesh(ar_ctx *ctx, uint32_t n_verts, uint32_t n_tris) {
     ctx->tripos_stride = (size_t(n_tris) + 63) / 64 * 64;
     AR_HIP(ctx, hipMalloc(&ctx->d_tripos, 9 * ctx->tripos_stride * sizeof(float)));
     AR_HIP(ctx, hipMalloc(&ctx->d_triattr, size_t(n_tris) * 24 * sizeof(float)));
-    for (int k = 0; k < kSets; k++) AR_HIP(ctx, hipMalloc(&ctx->d_records[k], 2 * size_t(n_tris) * sizeof(BinRec)));
-    AR_HIP(ctx, hipMalloc(&ctx->d_flat, size_t(n_tris)));
+    AR_HIP(ctx, hipMalloc(&ctx->d_tri, size_t(n_tris) * sizeof(TriStatic)));
     k_tristream<<<(n_tris + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_vbo, ctx->d_idx, n_verts, n_tris, ctx->tripos_stride, ctx->d_tripos,
-                                                              ctx->d_triattr, ctx->d_flat);
+                                                              ctx->d_triattr, ctx->d_tri);
     AR_HIP(ctx, hipGetLastError());
     AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_verts = n_verts; ctx->n_tris = n_tris;
@@ -287,12 +285,13 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
             rc = sync_streams(ctx);
             if (rc) return rc;
             for (int k = 0; k < kSets; k++) {
-                (void)hipFree(ctx->d_surv[k]); (void)hipFree(ctx->d_surv_count[k]);
-                ctx->d_surv[k] = nullptr; ctx->d_surv_count[k] = nullptr;
+                (void)hipFree(ctx->d_surv[k]); (void)hipFree(ctx->d_sid[k]); (void)hipFree(ctx->d_surv_count[k]);
+                ctx->d_surv[k] = nullptr; ctx->d_sid[k] = nullptr; ctx->d_surv_count[k] = nullptr;
             }
             ctx->group_cap = 0;
             for (int k = 0; k < kSets; k++) {
                 AR_HIP(ctx, hipMalloc(&ctx->d_surv[k], want_groups * sizeof(uint2)));
+                AR_HIP(ctx, hipMalloc(&ctx->d_sid[k], want_groups * sizeof(uint32_t)));
                 AR_HIP(ctx, hipMalloc(&ctx->d_surv_count[k], (size_t(kMaxGroups) + 1) * sizeof(uint32_t)));
             }
             ctx->group_cap = want_groups;
@@ -328,8 +327,8 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
         uint32_t *blocksum = dircount + ctx->dircount_cap;
         {
             Stamper s(ctx, K_SETUP, fs);
-            k_setup<<<fp.n_groups, kSetupThreads, 0, fs>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_flat, ctx->d_records[set],
-                                                         ctx->d_surv[set], ctx->d_surv_count[set], dircount);
+            k_setup<<<fp.n_groups, kSetupThreads, 0, fs>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_surv[set], ctx->d_sid[set],
+                                                         ctx->d_surv_count[set], dircount);
         }
         {
             Stamper s(ctx, K_BINSCAN, fs);
@@ -337,15 +336,15 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
         }
         {
             Stamper s(ctx, K_FILL, fs);
-            k_fill<<<fp.n_groups, kSetupThreads, 0, fs>>>(fp, ctx->d_records[set], ctx->d_surv[set], ctx->d_surv_count[set], dircount, blocksum,
+            k_fill<<<fp.n_groups, kSetupThreads, 0, fs>>>(fp, ctx->d_tri, ctx->d_surv[set], ctx->d_sid[set], ctx->d_surv_count[set], dircount, blocksum,
                                                         ctx->d_state, ctx->d_entries[set], ctx->pool_cap, ctx->d_vis[set]);
         }
         {
             Stamper s(ctx, K_TILE, fs);
             const unsigned grid = unsigned((nbins + 7) / 8 * 8) << (2 * fp.bshift);
             auto kernel = textured ? k_tile<true> : k_tile<false>;
-            kernel<<<grid, 256, 0, fs>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_tripos, ctx->tripos_stride, ctx->d_triuv,
-                                         ctx->d_atlas, ctx->d_records[set], ctx->d_entries[set], ctx->pool_cap, ctx->d_state,
+            kernel<<<grid, 256, 0, fs>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_triuv,
+                                         ctx->d_atlas, ctx->d_tri, ctx->d_entries[set], ctx->pool_cap, ctx->d_state,
                                          ctx->d_vis[set], ctx->d_rgba[oset], ctx->d_depth[oset], ascii_out, ctx->d_ridx[set],
                                          ctx->d_ids[oset]);
         }

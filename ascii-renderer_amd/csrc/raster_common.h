@@ -34,7 +34,7 @@ struct FrameParams {
     int bshift;      // a bin is (1 << bshift)^2 tiles: 0 while the tiles fit the bin table, else 1
     uint32_t chunk, n_groups;  // triangles per k_setup workgroup, number of those workgroups
     uint32_t frame;  // frame counter
-    int set;         // buffer set of this frame (frame % kSets): binning state block, record slots, ...
+    int set;         // buffer set of this frame (frame % kSets): binning state block, survivor slots, ...
     int tex_w, tex_h;  // atlas size in texels; 0 x 0 while texturing is off
     uint8_t ramp[AR_MAX_RAMP];
 };

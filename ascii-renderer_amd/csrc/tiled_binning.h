@@ -11,24 +11,29 @@ namespace {
 //   k_tristream (at mesh upload) gathers, per triangle, the three positions into nine planes of
 //             n_tris floats (36 contiguous, coalesced bytes per triangle for the per-frame pass),
 //             the three vertices' normals and colours into one 96-byte row (one gather per shaded
-//             cell instead of index -> vertex chasing) and a flag telling whether the triangle is
-//             flat (identical normal and colour at its three vertices).
-//   k_setup   one pass over the positions, one triangle per lane and pass: transform, near clip,
-//             cull, cell range.  Every sub-triangle that can produce fragments gets a 64-byte setup
-//             record in the workgroup's block of record slots (dense, in triangle order), a 16-byte
-//             tuple for k_fill, and is counted into the workgroup's LDS histogram over bins, which
-//             is then published as one row of the count table.
+//             cell of a smooth triangle instead of index -> vertex chasing) and one 64-byte triangle
+//             record (positions, flat normal and colour, flags) that is all a tile needs of a flat
+//             triangle.  None of this changes from frame to frame.
+//   k_setup   one pass over the position planes, one triangle per lane and pass: transform, near
+//             clip, cull, cell range.  Every sub-triangle that can produce fragments leaves an
+//             8-byte tuple (cell range) and its id 2*triangle + sub in the workgroup's block of
+//             survivor slots (dense, in triangle order), and is counted into the workgroup's LDS
+//             histogram over bins, which is then published as one row of the count table.
 //   k_binscan column-wise exclusive prefix of the count table over the k_setup workgroups (in
 //             place, two levels) and per-row-block bin totals: every (workgroup, bin) pair gets a
 //             fixed slice of the bin's entry array without a single global atomic.
 //   k_fill    bin totals -> start of every bin's entry array (each workgroup scans them for itself), then
-//             every k_setup workgroup's survivors become one entry (record slot, mask of the bin's
-//             tiles the cell range touches) per (survivor, bin), written into that workgroup's slice.
+//             every k_setup workgroup's survivors become one entry (id, mask of the bin's tiles the
+//             cell range touches) per (survivor, bin), written into that workgroup's slice.
 //   k_tile    one workgroup per tile: filters its bin's entries by mask bit into an LDS work list,
-//             rasterises those records into a 2048-entry LDS key tile with LDS atomic min (small
-//             cell ranges: one lane per record; large ones: staged in LDS, one wavefront sweeps each), then shades
-//             the covered cells and writes the tile's RGBA / depth / ramp-index rows.  Visibility
-//             keys never touch HBM.
+//             fetches the listed triangles' records, redoes their setup (same expressions as k_setup,
+//             hence the same values) and rasterises them into a 2048-entry LDS key tile with LDS
+//             atomic min (small cell ranges: one lane per triangle; large ones: staged in LDS, one
+//             wavefront sweeps each), then shades the covered cells and writes the tile's RGBA /
+//             depth / ramp-index rows.  Visibility keys never touch HBM, and no per-frame setup
+//             result does either: a scattered 64-byte read costs the memory side a whole request
+//             whether it fetches a setup record or the static triangle, and the static triangle
+//             does not have to be written first.
 // If the entry pool cannot hold a bin, the sub-triangles touching that bin are rasterised straight
 // into a global key buffer by k_fill, which also raises the frame's overflow flag, and k_tile merges
 // that buffer in.
@@ -42,24 +47,27 @@ constexpr int kMaxTiles = 8000;       // tiles per frame the tiled path accepts
 constexpr int kMaxBins = 2048;        // >= kMaxTiles / 4 for any tile-grid shape the path accepts
 constexpr int kSetupThreads = 256;    // k_setup / k_fill workgroup size
 constexpr uint32_t kMaxGroups = 1024;  // k_setup workgroups (rows of the count table)
-constexpr int kTileBigMax = 512;      // per-tile list of records swept cooperatively
+constexpr int kTileBigMax = 512;      // per-tile list of triangles swept cooperatively
 constexpr int kTileStage = 64;        // of which so many are staged in LDS at a time (64 B each, in the cell list's 4 KB)
 constexpr int kTileSmallCells = 64;   // cell-range area (inside the tile) one lane scans itself
 constexpr int kTileListMax = 2048;    // ids staged in LDS between the filter and the raster step
-constexpr int kEntryMaskShift = 28;   // a bin entry is (record slot) | (mask of the bin's 2x2 tiles) << 28
+constexpr int kEntryMaskShift = 28;   // a bin entry is (2*triangle + sub) | (mask of the bin's 2x2 tiles) << 28
 constexpr uint32_t kEntryLocMask = (1u << kEntryMaskShift) - 1u;
 constexpr int kFilterBatch = 4;       // bin entries a k_tile lane loads per filter step
-constexpr uint32_t kFlagClipped = 1u; // record produced by the near-plane clip (vertices differ from the mesh's)
 constexpr uint32_t kFlagFlat = 2u;    // the triangle's three vertices carry identical normal and colour
 constexpr uint32_t kFlagTextured = 4u;  // the triangle samples the atlas (set from its texel-coordinate row)
 
-struct __align__(16) BinRec {
-    float X[3], Y[3], W[3], Z[3];
-    uint32_t id;              // 2*triangle + sub-triangle
-    uint16_t i0, i1, j0, j1;  // inclusive cell range, GL window rows (y up)
-    uint32_t flags;           // kFlagClipped | kFlagFlat | kFlagTextured
+// One triangle as the per-tile resolve wants it, written once per mesh: one 64-byte line holds the three
+// positions, the flat normal and colour (valid when kFlagFlat is set) and the flags.  A tile fetches the
+// triangles binned to it by this record alone and redoes the few hundred operations of their setup, instead
+// of reading a per-frame setup record that another kernel had to write first.
+struct __align__(16) TriStatic {
+    float p[9];      // positions of the three vertices
+    float n[3];      // normal (flat triangles)
+    float c[3];      // colour (flat triangles)
+    uint32_t flags;  // kFlagFlat | kFlagTextured
 };
-static_assert(sizeof(BinRec) == 64, "bin records are four 16-byte loads");
+static_assert(sizeof(TriStatic) == 64, "triangle records are four 16-byte loads");
 
 // Per-frame binning state; one block per buffer set.
 struct BinState {
@@ -97,12 +105,13 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
 
 // Per triangle: positions -> planes pos[k*stride + t] (k = 3*vertex + axis); normal and colour of each
 // vertex -> attr[t*24 + 8*v ..] = (nx, ny, nz, r, g, b, 0, 0), so a vertex is one 16-byte plus one
-// 8-byte load; flat[t] = kFlagFlat when the three normals and the three colours are identical.
+// 8-byte load; tri[t] = the triangle's 64-byte record, kFlagFlat set when the three normals and the three
+// colours are identical.
 // A triangle that names a vertex outside the buffer gets NaN positions, which every later stage rejects.
 __global__ __launch_bounds__(256) void k_tristream(const float *__restrict__ vbo, const uint32_t *__restrict__ idx,
                                                    uint32_t n_verts, uint32_t n_tris, size_t stride,
                                                    float *__restrict__ pos, float *__restrict__ attr,
-                                                   uint8_t *__restrict__ flat) {
+                                                   TriStatic *__restrict__ tri) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n_tris) return;
     float a[3][9];
@@ -127,7 +136,15 @@ __global__ __launch_bounds__(256) void k_tristream(const float *__restrict__ vbo
 #pragma unroll
         for (int q = 3; q < 9; q++) is_flat = is_flat && (__float_as_uint(a[v][q]) == __float_as_uint(a[0][q]));
     }
-    flat[t] = is_flat ? uint8_t(kFlagFlat) : uint8_t(0);
+    TriStatic r;
+#pragma unroll
+    for (int v = 0; v < 3; v++)
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) r.p[3 * v + ax] = all_ok || idx[3 * size_t(t) + v] < n_verts ? a[v][ax] : __builtin_nanf("");
+#pragma unroll
+    for (int q = 0; q < 3; q++) { r.n[q] = a[0][3 + q]; r.c[q] = a[0][6 + q]; }
+    r.flags = is_flat ? kFlagFlat : 0u;
+    tri[t] = r;
 }
 
 // Indexed mesh -> the reference's unshared, flat-shaded vertex buffer (what _rebuildGeometry's pushTri emits
@@ -168,11 +185,11 @@ __global__ __launch_bounds__(256) void k_build_vbo(const float *__restrict__ pos
 
 // Copies the "sample the atlas" bit of every triangle's texel-coordinate row into its flag byte (all bits
 // cleared when triuv is null).
-__global__ __launch_bounds__(256) void k_uvflags(const uint4 *__restrict__ triuv, uint32_t n_tris, uint8_t *__restrict__ flat) {
+__global__ __launch_bounds__(256) void k_uvflags(const uint4 *__restrict__ triuv, uint32_t n_tris, TriStatic *__restrict__ tri) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n_tris) return;
     const bool sample = triuv && (triuv[t].w & kUvSample) != 0u;
-    flat[t] = uint8_t((flat[t] & ~kFlagTextured) | (sample ? kFlagTextured : 0u));
+    tri[t].flags = (tri[t].flags & ~kFlagTextured) | (sample ? kFlagTextured : 0u);
 }
 
 __device__ __forceinline__ Vert<0> transform_position(const FrameParams &fp, float x, float y, float z) {
@@ -216,26 +233,51 @@ __device__ __forceinline__ void triangle_setup(const FrameParams &fp, const floa
     }
 }
 
-__device__ __forceinline__ BinRec make_record(const Candidate &c, uint32_t id, uint32_t flags) {
-    BinRec r;
-#pragma unroll
-    for (int q = 0; q < 3; q++) { r.X[q] = c.sc.X[q]; r.Y[q] = c.sc.Y[q]; r.W[q] = c.sc.W[q]; r.Z[q] = c.sc.Z[q]; }
-    r.id = id;
-    r.i0 = uint16_t(c.i0); r.i1 = uint16_t(c.i1); r.j0 = uint16_t(c.j0); r.j1 = uint16_t(c.j1);
-    r.flags = flags;
-    return r;
+// to_screen for a sub-triangle k_setup has binned: its vertices are known to be finite with w > 0.
+__device__ __forceinline__ void to_screen_valid(const float (&c0)[4], const float (&c1)[4], const float (&c2)[4], float hw,
+                                                float hh, Screen &s) {
+    s.W[0] = c0[3]; s.W[1] = c1[3]; s.W[2] = c2[3];
+    s.Z[0] = c0[2]; s.Z[1] = c1[2]; s.Z[2] = c2[2];
+    s.X[0] = (c0[0] + c0[3]) * hw; s.X[1] = (c1[0] + c1[3]) * hw; s.X[2] = (c2[0] + c2[3]) * hw;
+    s.Y[0] = (c0[1] + c0[3]) * hh; s.Y[1] = (c1[1] + c1[3]) * hh; s.Y[2] = (c2[1] + c2[3]) * hh;
 }
 
-// Workgroup g owns record slots [g * 2 * chunk, (g + 1) * 2 * chunk) and fills them densely, in
-// triangle order: a record's slot number ("loc") therefore grows with its id, and visibility keys
-// carry loc in place of the id - same tie-break, and the winner's record is found without a lookup.
-// surv: the cell ranges of the same slots, (i0 | i1 << 16, j0 | j1 << 16), all k_fill needs of a record.
+// sub_triangle_screen (below) for a sub-triangle that k_setup has binned: no validity tests.
+__device__ __forceinline__ void binned_triangle_screen(const FrameParams &fp, const float (&p)[9], uint32_t sub, Screen &sc,
+                                                       bool &clipped) {
+    const Vert<0> in0 = transform_position(fp, p[0], p[1], p[2]), in1 = transform_position(fp, p[3], p[4], p[5]),
+                  in2 = transform_position(fp, p[6], p[7], p[8]);
+    clipped = !(in0.c[2] + in0.c[3] >= 0.0f) || !(in1.c[2] + in1.c[3] >= 0.0f) || !(in2.c[2] + in2.c[3] >= 0.0f);
+    if (!clipped) { to_screen_valid(in0.c, in1.c, in2.c, fp.hw, fp.hh, sc); return; }
+    Vert<0> s0[3], s1[3];
+    clip_near<0>(in0, in1, in2, s0, s1);
+    if (sub) to_screen_valid(s1[0].c, s1[1].c, s1[2].c, fp.hw, fp.hh, sc);
+    else to_screen_valid(s0[0].c, s0[1].c, s0[2].c, fp.hw, fp.hh, sc);
+}
+
+// Screen-space vertices of sub-triangle `sub` of the triangle with positions p: the transform, near clip and
+// screen mapping of triangle_setup, for one sub-triangle.  clipped: the near plane cut the triangle.  False when
+// the sub-triangle does not exist or cannot produce fragments (never the case for one that k_setup binned).
+__device__ __forceinline__ bool sub_triangle_screen(const FrameParams &fp, const float (&p)[9], uint32_t sub, Screen &sc,
+                                                    bool &clipped) {
+    const Vert<0> in0 = transform_position(fp, p[0], p[1], p[2]), in1 = transform_position(fp, p[3], p[4], p[5]),
+                  in2 = transform_position(fp, p[6], p[7], p[8]);
+    clipped = !(in0.c[2] + in0.c[3] >= 0.0f) || !(in1.c[2] + in1.c[3] >= 0.0f) || !(in2.c[2] + in2.c[3] >= 0.0f);
+    if (!clipped) return sub == 0u && to_screen(in0.c, in1.c, in2.c, fp.hw, fp.hh, sc);
+    Vert<0> s0[3], s1[3];
+    const int ns = clip_near<0>(in0, in1, in2, s0, s1);
+    if (int(sub) >= ns) return false;
+    return sub ? to_screen(s1[0].c, s1[1].c, s1[2].c, fp.hw, fp.hh, sc) : to_screen(s0[0].c, s0[1].c, s0[2].c, fp.hw, fp.hh, sc);
+}
+
+// Workgroup g owns survivor slots [g * 2 * chunk, (g + 1) * 2 * chunk) and fills them densely, in triangle
+// order.  surv: the cell range of a survivor, (i0 | i1 << 16, j0 | j1 << 16); sid: its id 2*triangle + sub -
+// all k_fill needs.  Nothing else of the setup is kept: the tiles redo it from the triangle records.
 // One triangle per lane and pass; chunk is a multiple of the workgroup size (one pass up to about
 // four million triangles).
 __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const float *__restrict__ tripos, size_t stride,
-                                                         const uint8_t *__restrict__ flat, BinRec *__restrict__ records,
-                                                         uint2 *__restrict__ surv, uint32_t *__restrict__ surv_count,
-                                                         uint32_t *__restrict__ dircount) {
+                                                         uint2 *__restrict__ surv, uint32_t *__restrict__ sid,
+                                                         uint32_t *__restrict__ surv_count, uint32_t *__restrict__ dircount) {
     __shared__ uint32_t hist[kMaxBins];
     __shared__ uint32_t s_wave[kSetupThreads / 64];
     const uint32_t tid = threadIdx.x;
@@ -253,14 +295,11 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const f
         const bool live = t < t_end;
         Candidate c[2];
         bool have[2] = {false, false}, clipped = false;
-        uint32_t flags = 0;
         if (live) {
             float p[9];
 #pragma unroll
             for (int q = 0; q < 9; q++) p[q] = tripos[size_t(q) * stride + t];
-            flags = flat[t];  // kFlagFlat | kFlagTextured
             triangle_setup(fp, p, jlo, jhi, c, have, clipped);
-            if (clipped) flags |= kFlagClipped;
         }
         uint32_t total;
         uint32_t slot = run + block_exclusive_scan<kSetupThreads / 64>(uint32_t(have[0]) + uint32_t(have[1]), s_wave, total);
@@ -270,7 +309,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const f
             if (!have[s]) continue;
             const uint32_t loc = loc_base + slot;
             slot++;
-            records[loc] = make_record(c[s], 2u * t + uint32_t(s), flags);
+            sid[loc] = 2u * t + uint32_t(s);
             surv[loc] = make_uint2(uint32_t(c[s].i0) | (uint32_t(c[s].i1) << 16), uint32_t(c[s].j0) | (uint32_t(c[s].j1) << 16));
             int bx0, bx1, by0, by1;
             bin_range(fp, c[s].i0, c[s].i1, c[s].j0, c[s].j1, bx0, bx1, by0, by1);
@@ -328,8 +367,8 @@ __global__ __launch_bounds__(1024) void k_binscan(FrameParams fp, uint32_t *__re
 // start of the bin + entries of earlier row blocks + entries of earlier workgroups of its own row block (the
 // scanned table).  The totals are 16 x bins words read from L2 per workgroup; recomputing them here saves the frame
 // a kernel whose only job was this scan.  Workgroup 0 also publishes start / total / overflow for k_tile.
-__global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const BinRec *__restrict__ records,
-                                                        const uint2 *__restrict__ surv,
+__global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const TriStatic *__restrict__ tri,
+                                                        const uint2 *__restrict__ surv, const uint32_t *__restrict__ sid,
                                                         const uint32_t *__restrict__ surv_count,
                                                         const uint32_t *__restrict__ dircount,
                                                         const uint32_t *__restrict__ blocksum, BinState *__restrict__ state,
@@ -385,8 +424,9 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Bi
     __syncthreads();
     const uint32_t loc_base = blockIdx.x * 2u * fp.chunk;
     for (uint32_t s = tid; s < n; s += kSetupThreads) {
-        const uint32_t loc = loc_base + s;  // record slot; also what the visibility keys carry
+        const uint32_t loc = loc_base + s;
         const uint2 sv = surv[loc];
+        const uint32_t id = sid[loc];  // 2*triangle + sub: what entries and visibility keys carry
         const int i0 = int(sv.x & 0xFFFFu), i1 = int(sv.x >> 16), j0 = int(sv.y & 0xFFFFu), j1 = int(sv.y >> 16);
         const int r0 = fp.rows - 1 - j1 - fp.ya, r1 = fp.rows - 1 - j0 - fp.ya;  // rows relative to the strip
         const int tx0 = i0 >> 6, tx1 = i1 >> 6, ty0 = r0 >> kTileShiftH, ty1 = r1 >> kTileShiftH;
@@ -404,16 +444,20 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Bi
                 const uint32_t rowbits = ((1u << (ax1 + 1)) - 1u) & ~((1u << ax0) - 1u);
                 uint32_t m = 0;
                 for (int ay = ay0; ay <= ay1; ay++) m |= rowbits << (side * ay);
-                entries[size_t(base[b]) + atomicAdd(&cnt[b], 1u)] = loc | (m << kEntryMaskShift);
+                entries[size_t(base[b]) + atomicAdd(&cnt[b], 1u)] = id | (m << kEntryMaskShift);
             }
         if (direct) {  // a bin it touches has no room: resolve through the global key buffer
+            const TriStatic ts = tri[id >> 1];
+            Screen sc;
+            bool clipped;
+            if (!sub_triangle_screen(fp, ts.p, id & 1u, sc, clipped)) continue;
             Edges e;
-            edges_from_screen(records[loc], e);
+            edges_from_screen(sc, e);
             for (int j = j0; j <= j1; j++) {
                 const size_t row = size_t(fp.rows - 1 - j) * fp.cols;
                 for (int i = i0; i <= i1; i++) {
                     float f[3], zw;
-                    if (cover(e, i, j, f, zw)) vis_min(vis, row + i, make_key(zw, loc));
+                    if (cover(e, i, j, f, zw)) vis_min(vis, row + i, make_key(zw, id));
                 }
             }
         }

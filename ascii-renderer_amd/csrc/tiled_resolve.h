@@ -4,7 +4,7 @@
 
 namespace {
 
-// Colour of cell (i, j) for a record the near plane cut.  The record holds the sub-triangle's screen
+// Colour of cell (i, j) for a sub-triangle the near plane cut.  sc holds the sub-triangle's screen
 // vertices, so only the varyings of its three vertices are missing: each is a mesh vertex or the point
 // I + (O - I) * (dI / (dI - dO)) on the edge from an inside vertex I to an outside vertex O, exactly as
 // clip_near builds them.  Which is which follows from the signs of d = z_c + w_c of the three mesh
@@ -13,9 +13,9 @@ namespace {
 template <bool TEX>
 __device__ __forceinline__ void shade_clipped_record(const FrameParams &fp, const float *__restrict__ vbo,
                                                      const uint32_t *__restrict__ idx, const uint4 *__restrict__ triuv,
-                                                     const uint32_t *__restrict__ atlas, const BinRec &rec, int i, int j,
-                                                     uint8_t (&px)[4]) {
-    const uint32_t t = rec.id >> 1, sub = rec.id & 1u;
+                                                     const uint32_t *__restrict__ atlas, const Screen &sc, uint32_t id,
+                                                     uint32_t flags, int i, int j, uint8_t (&px)[4]) {
+    const uint32_t t = id >> 1, sub = id & 1u;
     const float *vp[3];
     float d[3];
 #pragma unroll
@@ -44,7 +44,7 @@ __device__ __forceinline__ void shade_clipped_record(const FrameParams &fp, cons
         tt[m] = dI / (dI - dO);
     }
     Edges e;
-    edges_from_screen(rec, e);
+    edges_from_screen(sc, e);
     const double pxd = double(i) + 0.5, pyd = double(j) + 0.5;
     float f[3];
 #pragma unroll
@@ -64,7 +64,7 @@ __device__ __forceinline__ void shade_clipped_record(const FrameParams &fp, cons
     };
     float v[9];
     for (int q = 0; q < 9; q++) v[q] = varying(vp[0][q], vp[1][q], vp[2][q]);
-    if (TEX && (rec.flags & kFlagTextured)) {
+    if (TEX && (flags & kFlagTextured)) {
         const uint4 uv = triuv[t];
         const float tu = varying(float(uv.x & 0xFFFFu), float(uv.y & 0xFFFFu), float(uv.z & 0xFFFFu));
         const float tv = varying(float(uv.x >> 16), float(uv.y >> 16), float(uv.z >> 16));
@@ -73,27 +73,37 @@ __device__ __forceinline__ void shade_clipped_record(const FrameParams &fp, cons
     shade(fp, v, px);
 }
 
-// Colour and depth of cell (i, j) from the winner's setup record; unclipped records take normal and
-// colour from the triangle's attribute row (one vertex's worth when the triangle is flat) and world
-// positions from the position planes (only when point lights are on); clipped ones are rebuilt by
-// shade_cell.
+// Colour and depth of cell (i, j) from the winner's triangle record: its setup is redone (same expressions as
+// k_setup, so the same values), then a flat triangle takes normal and colour from the record itself, any other
+// from its attribute row; world positions (point lights) are the record's.  Clipped sub-triangles go through
+// shade_clipped_record.
 template <bool TEX>
-__device__ __forceinline__ void shade_from_record(const FrameParams &fp, const float *__restrict__ vbo,
-                                                  const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
-                                                  const float *__restrict__ tripos, size_t stride,
-                                                  const uint4 *__restrict__ triuv, const uint32_t *__restrict__ atlas,
-                                                  const BinRec &rec, int i, int j, uint8_t (&px)[4], float &zw) {
-    if (rec.flags & kFlagClipped) { shade_clipped_record<TEX>(fp, vbo, idx, triuv, atlas, rec, i, j, px); return; }  // zw: the key's
-    const uint32_t t = rec.id >> 1;
-    const float4 *row = reinterpret_cast<const float4 *>(triattr) + size_t(t) * 6;
-    const int o1 = (rec.flags & kFlagFlat) ? 0 : 2, o2 = (rec.flags & kFlagFlat) ? 0 : 4;
-    const float4 a0 = row[0], a1 = row[o1], a2 = row[o2];
-    const float2 c0 = *reinterpret_cast<const float2 *>(row + 1), c1 = *reinterpret_cast<const float2 *>(row + o1 + 1),
-                 c2 = *reinterpret_cast<const float2 *>(row + o2 + 1);
+__device__ __forceinline__ void shade_from_triangle(const FrameParams &fp, const float *__restrict__ vbo,
+                                                    const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
+                                                    const uint4 *__restrict__ triuv, const uint32_t *__restrict__ atlas,
+                                                    const TriStatic &ts, uint32_t id, int i, int j, uint8_t (&px)[4], float &zw) {
+    Screen sc;
+    bool clipped;
+    binned_triangle_screen(fp, ts.p, id & 1u, sc, clipped);
+    if (clipped) { shade_clipped_record<TEX>(fp, vbo, idx, triuv, atlas, sc, id, ts.flags, i, j, px); return; }  // zw: the key's
+    const uint32_t t = id >> 1;
+    float4 a0, a1, a2;
+    float2 c0, c1, c2;
+    if (ts.flags & kFlagFlat) {
+        a0 = a1 = a2 = make_float4(ts.n[0], ts.n[1], ts.n[2], ts.c[0]);
+        c0 = c1 = c2 = make_float2(ts.c[1], ts.c[2]);
+    } else {
+        const float4 *row = reinterpret_cast<const float4 *>(triattr) + size_t(t) * 6;
+        a0 = row[0]; a1 = row[2]; a2 = row[4];
+        c0 = *reinterpret_cast<const float2 *>(row + 1); c1 = *reinterpret_cast<const float2 *>(row + 3);
+        c2 = *reinterpret_cast<const float2 *>(row + 5);
+    }
     Edges e;
-    edges_from_screen(rec, e);
+    edges_from_screen(sc, e);
+    const double pxd = double(i) + 0.5, pyd = double(j) + 0.5;  // (the cell is covered and its depth is the key's: no test here)
     float f[3];
-    cover(e, i, j, f, zw);
+#pragma unroll
+    for (int k = 0; k < 3; k++) f[k] = float(e.a[k] * pxd + (e.b[k] * pyd + e.c[k]));
     const float rS = 1.0f / ((f[0] + f[1]) + f[2]);
     const float b0 = f[0] * rS, b1 = f[1] * rS, b2 = f[2] * rS;
     float v[9];
@@ -104,15 +114,12 @@ __device__ __forceinline__ void shade_from_record(const FrameParams &fp, const f
     v[7] = (b0 * c0.x + b1 * c1.x) + b2 * c2.x;
     v[8] = (b0 * c0.y + b1 * c1.y) + b2 * c2.y;
     if (fp.n_pl > 0) {
-        float p[9];
 #pragma unroll
-        for (int q = 0; q < 9; q++) p[q] = tripos[size_t(q) * stride + t];
-#pragma unroll
-        for (int q = 0; q < 3; q++) v[q] = (b0 * p[q] + b1 * p[3 + q]) + b2 * p[6 + q];
+        for (int q = 0; q < 3; q++) v[q] = (b0 * ts.p[q] + b1 * ts.p[3 + q]) + b2 * ts.p[6 + q];
     } else {
         v[0] = v[1] = v[2] = 0.0f;  // only the point-light loop reads the position
     }
-    if (TEX && (rec.flags & kFlagTextured)) {
+    if (TEX && (ts.flags & kFlagTextured)) {
         const uint4 uv = triuv[t];
         const float tu = (b0 * float(uv.x & 0xFFFFu) + b1 * float(uv.y & 0xFFFFu)) + b2 * float(uv.z & 0xFFFFu);
         const float tv = (b0 * float(uv.x >> 16) + b1 * float(uv.y >> 16)) + b2 * float(uv.z >> 16);
@@ -197,9 +204,8 @@ __device__ __forceinline__ void raster_range(const FrameParams &fp, const Edges 
 template <bool TEX>
 __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__restrict__ vbo,
                                               const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
-                                              const float *__restrict__ tripos, size_t stride,
                                               const uint4 *__restrict__ triuv, const uint32_t *__restrict__ atlas,
-                                              const BinRec *__restrict__ records,
+                                              const TriStatic *__restrict__ tri,
                                               const uint32_t *__restrict__ entries, uint32_t entries_cap,
                                               const BinState *__restrict__ state, uint64_t *__restrict__ vis,
                                               uint8_t *__restrict__ rgba, float *__restrict__ depth,
@@ -223,6 +229,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
     const int tx0 = tile_x * kTileW, tr0 = fp.ya + tile_y * kTileH;                      // first column / output row
     const int tx1 = min(tx0 + kTileW, fp.cols) - 1, tr1 = min(tr0 + kTileH, fp.yb) - 1;  // last column / row
     const uint32_t bit = 1u << sub;
+    const int jlo = fp.rows - fp.yb, jhi = fp.rows - 1 - fp.ya;  // window rows of the frame's strip, as in k_setup
     const BinState &st = state[fp.set];
     for (int c = int(tid); c < kTileCells; c += 256) keys[c] = kBackgroundKey;
     if (tid == 0) { n_list = 0; n_big = 0; n_cov = 0; }
@@ -249,48 +256,60 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
         const uint32_t nl = n_list;
         const bool last = eb + 256 * kFilterBatch >= e_end;
         if (nl + 256 * kFilterBatch > uint32_t(kTileListMax) || last) {
-            // records with a small cell range inside the tile: one lane each; others -> sweep list
-            // (a lane's next record is fetched while it works on the current one)
-            BinRec ahead;
-            if (tid < nl) ahead = records[list[tid]];
+            // sub-triangles with a small cell range inside the tile: one lane each; others -> sweep list
+            // (a lane's next triangle record is fetched while it works on the current one)
+            TriStatic ahead;
+            if (tid < nl) ahead = tri[list[tid] >> 1];
             for (uint32_t r = tid; r < nl; r += 256) {
-                const uint32_t loc = list[r];
-                const BinRec rec = ahead;
-                if (r + 256 < nl) ahead = records[list[r + 256]];
-                const int i0 = max(int(rec.i0), tx0), i1 = min(int(rec.i1), tx1);
-                const int r0 = max(fp.rows - 1 - int(rec.j1), tr0), r1 = min(fp.rows - 1 - int(rec.j0), tr1);
+                const uint32_t id = list[r];
+                const TriStatic ts = ahead;
+                if (r + 256 < nl) ahead = tri[list[r + 256] >> 1];
+                Screen sc;
+                bool clipped;
+                int ci0, ci1, cj0, cj1;
+                binned_triangle_screen(fp, ts.p, id & 1u, sc, clipped);
+                if (!cell_range(sc.X, sc.Y, sc.W, fp.cols, jlo, jhi, ci0, ci1, cj0, cj1)) continue;  // (binned: never empty)
+                const int i0 = max(ci0, tx0), i1 = min(ci1, tx1);
+                const int r0 = max(fp.rows - 1 - cj1, tr0), r1 = min(fp.rows - 1 - cj0, tr1);
                 if ((i1 - i0 + 1) * (r1 - r0 + 1) > kTileSmallCells) {
                     const uint32_t slot = atomicAdd(&n_big, 1u);
-                    if (slot < uint32_t(kTileBigMax)) { big[slot] = loc; continue; }
+                    if (slot < uint32_t(kTileBigMax)) { big[slot] = id; continue; }
                     // list full: this lane scans the range itself (slow but correct)
                 }
                 Edges ed;
-                edges_from_screen(rec, ed);
-                raster_range(fp, ed, loc, i0, i1, r0, r1, tx0, tr0, keys);
+                edges_from_screen(sc, ed);
+                raster_range(fp, ed, id, i0, i1, r0, r1, tx0, tr0, keys);
             }
             __syncthreads();
             // sweep list: the records are brought into LDS 64 at a time (one fetch latency per batch instead of
             // one per record), then every wavefront sweeps a record of its own, 64 cells per step
             const uint32_t nb = min(n_big, uint32_t(kTileBigMax));
-            BinRec *stage = reinterpret_cast<BinRec *>(covered);  // (the cell list is not in use before the raster step ends)
+            TriStatic *stage = reinterpret_cast<TriStatic *>(covered);  // (the cell list is not in use before the raster step ends)
             for (uint32_t b0 = 0; b0 < nb; b0 += kTileStage) {
                 const uint32_t ns = min(uint32_t(kTileStage), nb - b0);
-                if (tid < ns) stage[tid] = records[big[b0 + tid]];
+                if (tid < ns) stage[tid] = tri[big[b0 + tid] >> 1];
                 __syncthreads();
                 for (uint32_t q = tid >> 6; q < ns; q += 4) {
-                    const BinRec &rec = stage[q];
-                    const uint32_t loc = big[b0 + q];
-                    const int i0 = max(int(rec.i0), tx0), i1 = min(int(rec.i1), tx1);
-                    const int r0 = max(fp.rows - 1 - int(rec.j1), tr0), r1 = min(fp.rows - 1 - int(rec.j0), tr1);
+                    const uint32_t id = big[b0 + q];
+                    float p[9];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) p[k] = stage[q].p[k];
+                    Screen sc;
+                    bool clipped;
+                    int ci0, ci1, cj0, cj1;
+                    binned_triangle_screen(fp, p, id & 1u, sc, clipped);
+                    if (!cell_range(sc.X, sc.Y, sc.W, fp.cols, jlo, jhi, ci0, ci1, cj0, cj1)) continue;
+                    const int i0 = max(ci0, tx0), i1 = min(ci1, tx1);
+                    const int r0 = max(fp.rows - 1 - cj1, tr0), r1 = min(fp.rows - 1 - cj0, tr1);
                     const int w = i1 - i0 + 1, n = w * (r1 - r0 + 1);
                     Edges ed;
-                    edges_from_screen(rec, ed);
+                    edges_from_screen(sc, ed);
                     for (int k = int(tid & 63u); k < n; k += 64) {
                         const int dr = k / w, i = i0 + (k - dr * w), rr = r0 + dr;
                         float f[3], zw;
                         if (cover(ed, i, fp.rows - 1 - rr, f, zw))
                             atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
-                                      (unsigned long long)make_key(zw, loc));
+                                      (unsigned long long)make_key(zw, id));
                     }
                 }
                 __syncthreads();
@@ -325,11 +344,12 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
     for (uint32_t k = tid; k < nc; k += 256) {
         const int c = int(covered[k]);
         const int rr = tr0 + (c >> 6), i = tx0 + (c & 63);
-        const BinRec rec = records[uint32_t(keys[c])];  // the key's low word is the winner's record slot
+        const uint32_t id = uint32_t(keys[c]);  // the key's low word is the winner: 2*triangle + sub
+        const TriStatic ts = tri[id >> 1];
         uint8_t px[4];
-        float zw = __uint_as_float(uint32_t(keys[c] >> 32));  // the depth the raster pass computed from this record
-        shade_from_record<TEX>(fp, vbo, idx, triattr, tripos, stride, triuv, atlas, rec, i, fp.rows - 1 - rr, px, zw);
-        if (fp.want_ids) ids[size_t(rr) * fp.cols + i] = rec.id;
+        float zw = __uint_as_float(uint32_t(keys[c] >> 32));  // the depth the raster pass computed for this winner
+        shade_from_triangle<TEX>(fp, vbo, idx, triattr, triuv, atlas, ts, id, i, fp.rows - 1 - rr, px, zw);
+        if (fp.want_ids) ids[size_t(rr) * fp.cols + i] = id;
         keys[c] = (uint64_t(__float_as_uint(zw)) << 32) |
                   (uint32_t(px[0]) | (uint32_t(px[1]) << 8) | (uint32_t(px[2]) << 16) | (uint32_t(px[3]) << 24));
     }

@@ -159,9 +159,9 @@ def main():
     if rank == 0:
         cells = args.cols * (row1 - row0)
         per_launch_bytes = {                             # algorithmic bytes one launch must move
-            # tiled path: per-frame triangle stream is the derived position planes (36 B) + flat flag (1 B);
+            # tiled path: per-frame triangle stream is the derived position planes (36 B);
             # per cell RGBA8 4 + depth 4 + ramp index 1 written once, visibility keys stay in LDS
-            "k_setup": args.tris * 37,
+            "k_setup": args.tris * 36,
             "k_tile": cells * 9,
             "k_ascii": cells * 2,                        # ramp index in, ASCII code out
             "k_fill": counters["bin_records"] * 4,       # one 4-byte entry per (sub-triangle, bin)
