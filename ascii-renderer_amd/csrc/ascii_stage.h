@@ -160,7 +160,8 @@ __global__ __launch_bounds__(256) void k_ascii(FrameParams fp, const void *__res
 // A workgroup takes 128 x 8 cells, a lane four consecutive cells of one row.  The tile and its halo are
 // staged as bytes with rows padded so that a lane's window (its four cells and R neighbours on either
 // side) is three aligned dwords per row: 3 * (2R + 1) LDS reads serve four cells, and the neighbours are
-// byte fields of registers.  Same Boyer-Moore order and vote rule as k_ascii.
+// byte fields of registers.  Same Boyer-Moore order and vote rule as k_ascii (the plane holds no override cells,
+// so every neighbour votes).
 template <int R>
 __global__ __launch_bounds__(256) void k_ascii_plane(FrameParams fp, const uint8_t *__restrict__ src, uint8_t *__restrict__ ascii) {
     constexpr int TWD = 34, TH = 8 + 2 * R;  // dwords per tile row: 4 bytes of left halo, 128 cells, 4 of right halo
@@ -197,7 +198,10 @@ __global__ __launch_bounds__(256) void k_ascii_plane(FrameParams fp, const uint8
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         // byte p of a window row is column x - 4 + p; cell j sits at p = 4 + j
-        int cand = -1, cnt = 0, votes = 0;
+        // Boyer-Moore with the counter kept as hits: every step adds +1 or -1 (a reset takes the new value as
+        // candidate, which then matches itself), so after k neighbours the counter is 2 * hits - k and can only
+        // be zero - the reset condition - when k is even and hits == k / 2.
+        int cand = 0, hits = 0, votes = 0, k = 0;
 #pragma unroll
         for (int dy = -R; dy <= R; dy++)
 #pragma unroll
@@ -205,8 +209,9 @@ __global__ __launch_bounds__(256) void k_ascii_plane(FrameParams fp, const uint8
                 if (dx == 0 && dy == 0) continue;
                 const int p = 4 + j + dx;
                 const int ni = int((w[dy + R][p >> 2] >> (8 * (p & 3))) & 255u);
-                cand = cnt == 0 ? ni : cand;
-                cnt += ni == cand ? 1 : -1;
+                if ((k & 1) == 0) cand = (k == 0 || hits == k / 2) ? ni : cand;
+                hits += ni == cand ? 1 : 0;
+                k++;
             }
 #pragma unroll
         for (int dy = -R; dy <= R; dy++)
