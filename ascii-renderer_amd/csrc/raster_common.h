@@ -167,18 +167,29 @@ __device__ __forceinline__ bool front_facing(const Screen &s) {
 }
 
 // Inclusive cell range (GL window coordinates) that contains every covered cell centre, clamped to
-// the viewport columns and to window rows [jlo, jhi].  False when empty.
+// the viewport columns and to window rows [jlo, jhi].  False when empty.  The range only has to be a
+// superset (coverage is decided per cell in binary64), so the window coordinates come from the hardware
+// reciprocal: X * rcp(W) is within 2^-22 |X / W| of the quotient, at most 2^-6 of a cell for coordinates up
+// to 65536, and the half-cell offsets carry 2^-5 of slack.  W outside [2^-100, 2^100] (where the reciprocal
+// or the product could leave the normal range) takes the correctly rounded division.
 __device__ __forceinline__ bool cell_range(const float (&X)[3], const float (&Y)[3], const float (&W)[3], int cols,
                                            int jlo, int jhi, int &i0, int &i1, int &j0, int &j1) {
-    float minx = X[0] / W[0], maxx = minx, miny = Y[0] / W[0], maxy = miny;
+    const float wmin = fminf(fminf(W[0], W[1]), W[2]), wmax = fmaxf(fmaxf(W[0], W[1]), W[2]);
+    float sx[3], sy[3];
+    if (wmin >= 0x1p-100f && wmax <= 0x1p100f) {
 #pragma unroll
-    for (int k = 1; k < 3; k++) {
-        const float sx = X[k] / W[k], sy = Y[k] / W[k];
-        minx = fminf(minx, sx); maxx = fmaxf(maxx, sx);
-        miny = fminf(miny, sy); maxy = fmaxf(maxy, sy);
+        for (int k = 0; k < 3; k++) {
+            const float r = __builtin_amdgcn_rcpf(W[k]);
+            sx[k] = X[k] * r; sy[k] = Y[k] * r;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { sx[k] = X[k] / W[k]; sy[k] = Y[k] / W[k]; }
     }
-    const float lox = ceilf(fmaxf(minx - 0.50390625f, 0.0f)), hix = floorf(fminf(maxx - 0.49609375f, float(cols - 1)));
-    const float loy = ceilf(fmaxf(miny - 0.50390625f, float(jlo))), hiy = floorf(fminf(maxy - 0.49609375f, float(jhi)));
+    const float minx = fminf(fminf(sx[0], sx[1]), sx[2]), maxx = fmaxf(fmaxf(sx[0], sx[1]), sx[2]);
+    const float miny = fminf(fminf(sy[0], sy[1]), sy[2]), maxy = fmaxf(fmaxf(sy[0], sy[1]), sy[2]);
+    const float lox = ceilf(fmaxf(minx - 0.53125f, 0.0f)), hix = floorf(fminf(maxx - 0.46875f, float(cols - 1)));
+    const float loy = ceilf(fmaxf(miny - 0.53125f, float(jlo))), hiy = floorf(fminf(maxy - 0.46875f, float(jhi)));
     if (!(lox <= hix) || !(loy <= hiy)) return false;
     i0 = int(lox); i1 = int(hix); j0 = int(loy); j1 = int(hiy);
     return true;

@@ -103,6 +103,28 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
     return off + incl - v;
 }
 
+// block_exclusive_scan of h0 + h1 for lanes that each hold two flags: two ballots and their bit counts below
+// the lane take the place of the shuffle ladder.
+template <int NW>
+__device__ __forceinline__ uint32_t block_exclusive_scan_flags(bool h0, bool h1, uint32_t *s_wave, uint32_t &total) {
+    const uint32_t wave = threadIdx.x >> 6;
+    const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1);
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi(uint32_t(b0 >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(b0), 0u)) +
+                           __builtin_amdgcn_mbcnt_hi(uint32_t(b1 >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(b1), 0u));
+    if ((threadIdx.x & 63u) == 0u) s_wave[wave] = uint32_t(__popcll(b0)) + uint32_t(__popcll(b1));
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const uint32_t x = s_wave[w];
+        if (uint32_t(w) < wave) off += x;
+        tot += x;
+    }
+    total = tot;
+    __syncthreads();
+    return off + below;
+}
+
 // Per triangle: positions -> planes pos[k*stride + t] (k = 3*vertex + axis); normal and colour of each
 // vertex -> attr[t*24 + 8*v ..] = (nx, ny, nz, r, g, b, 0, 0), so a vertex is one 16-byte plus one
 // 8-byte load; tri[t] = the triangle's 64-byte record, kFlagFlat set when the three normals and the three
@@ -233,6 +255,10 @@ __device__ __forceinline__ void triangle_setup(const FrameParams &fp, const floa
     }
 }
 
+// Low word of a visibility key on the tiled path: the id, and below it whether the near plane cut the triangle
+// (the order of ids is kept; the shading step then knows without the clip-space z of the vertices).
+__device__ __forceinline__ uint32_t tile_key_low(uint32_t id, bool clipped) { return (id << 1) | uint32_t(clipped); }
+
 // to_screen for a sub-triangle k_setup has binned: its vertices are known to be finite with w > 0.
 __device__ __forceinline__ void to_screen_valid(const float (&c0)[4], const float (&c1)[4], const float (&c2)[4], float hw,
                                                 float hh, Screen &s) {
@@ -302,7 +328,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const f
             triangle_setup(fp, p, jlo, jhi, c, have, clipped);
         }
         uint32_t total;
-        uint32_t slot = run + block_exclusive_scan<kSetupThreads / 64>(uint32_t(have[0]) + uint32_t(have[1]), s_wave, total);
+        uint32_t slot = run + block_exclusive_scan_flags<kSetupThreads / 64>(have[0], have[1], s_wave, total);
         run += total;
 #pragma unroll
         for (int s = 0; s < 2; s++) {
@@ -457,7 +483,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Tr
                 const size_t row = size_t(fp.rows - 1 - j) * fp.cols;
                 for (int i = i0; i <= i1; i++) {
                     float f[3], zw;
-                    if (cover(e, i, j, f, zw)) vis_min(vis, row + i, make_key(zw, id));
+                    if (cover(e, i, j, f, zw)) vis_min(vis, row + i, make_key(zw, tile_key_low(id, clipped)));
                 }
             }
         }

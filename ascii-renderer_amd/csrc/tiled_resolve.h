@@ -81,11 +81,20 @@ template <bool TEX>
 __device__ __forceinline__ void shade_from_triangle(const FrameParams &fp, const float *__restrict__ vbo,
                                                     const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
                                                     const uint4 *__restrict__ triuv, const uint32_t *__restrict__ atlas,
-                                                    const TriStatic &ts, uint32_t id, int i, int j, uint8_t (&px)[4], float &zw) {
+                                                    const TriStatic &ts, uint32_t id, bool clipped, int i, int j,
+                                                    uint8_t (&px)[4]) {
     Screen sc;
-    bool clipped;
-    binned_triangle_screen(fp, ts.p, id & 1u, sc, clipped);
-    if (clipped) { shade_clipped_record<TEX>(fp, vbo, idx, triuv, atlas, sc, id, ts.flags, i, j, px); return; }  // zw: the key's
+    if (clipped) {
+        bool cut;
+        binned_triangle_screen(fp, ts.p, id & 1u, sc, cut);
+        shade_clipped_record<TEX>(fp, vbo, idx, triuv, atlas, sc, id, ts.flags, i, j, px);
+        return;
+    }
+    {   // (clip-space z is not needed: the depth is the key's)
+        const Vert<0> in0 = transform_position(fp, ts.p[0], ts.p[1], ts.p[2]), in1 = transform_position(fp, ts.p[3], ts.p[4], ts.p[5]),
+                      in2 = transform_position(fp, ts.p[6], ts.p[7], ts.p[8]);
+        to_screen_valid(in0.c, in1.c, in2.c, fp.hw, fp.hh, sc);
+    }
     const uint32_t t = id >> 1;
     float4 a0, a1, a2;
     float2 c0, c1, c2;
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
                 }
                 Edges ed;
                 edges_from_screen(sc, ed);
-                raster_range(fp, ed, id, i0, i1, r0, r1, tx0, tr0, keys);
+                raster_range(fp, ed, tile_key_low(id, clipped), i0, i1, r0, r1, tx0, tr0, keys);
             }
             __syncthreads();
             // sweep list: the records are brought into LDS 64 at a time (one fetch latency per batch instead of
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
                         float f[3], zw;
                         if (cover(ed, i, fp.rows - 1 - rr, f, zw))
                             atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
-                                      (unsigned long long)make_key(zw, id));
+                                      (unsigned long long)make_key(zw, tile_key_low(id, clipped)));
                     }
                 }
                 __syncthreads();
@@ -344,13 +353,13 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
     for (uint32_t k = tid; k < nc; k += 256) {
         const int c = int(covered[k]);
         const int rr = tr0 + (c >> 6), i = tx0 + (c & 63);
-        const uint32_t id = uint32_t(keys[c]);  // the key's low word is the winner: 2*triangle + sub
+        const uint32_t low = uint32_t(keys[c]);  // the key's low word is the winner: (2*triangle + sub) << 1 | clipped
+        const uint32_t id = low >> 1;
         const TriStatic ts = tri[id >> 1];
         uint8_t px[4];
-        float zw = __uint_as_float(uint32_t(keys[c] >> 32));  // the depth the raster pass computed for this winner
-        shade_from_triangle<TEX>(fp, vbo, idx, triattr, triuv, atlas, ts, id, i, fp.rows - 1 - rr, px, zw);
+        shade_from_triangle<TEX>(fp, vbo, idx, triattr, triuv, atlas, ts, id, (low & 1u) != 0u, i, fp.rows - 1 - rr, px);
         if (fp.want_ids) ids[size_t(rr) * fp.cols + i] = id;
-        keys[c] = (uint64_t(__float_as_uint(zw)) << 32) |
+        keys[c] = (keys[c] & 0xFFFFFFFF00000000ull) |  // (the depth the raster pass computed for this winner stays)
                   (uint32_t(px[0]) | (uint32_t(px[1]) << 8) | (uint32_t(px[2]) << 16) | (uint32_t(px[3]) << 24));
     }
     __syncthreads();
