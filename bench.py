@@ -57,6 +57,12 @@ def main():
                     help="take the strip + all-gather path even with one rank (rehearsal of the multi-GPU loop on one GPU)")
     args = ap.parse_args()
 
+    # stdout carries the one JSON line and nothing else: libraries that write to file descriptor 1 (RCCL prints a
+    # version banner there when a communicator is created) are sent to stderr for the rest of the run
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -210,7 +216,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ar, sc)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=result_out, flush=True)
     R.close()
     if gather:
         dist.barrier()

@@ -5,6 +5,8 @@ import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ar = importlib.import_module("ascii-renderer_amd")
+if os.environ.get("AR_LIB"):
+    ar.binding.LIB_PATH = os.environ["AR_LIB"]
 ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_raster_host.json")))
 scene = ref["scenes"]["default_scene"]
 vbo, idx = ar.host.build_geometry(scene)

@@ -1,6 +1,6 @@
 """Builds profiles/traffic.json (HBM bytes per launch and kernel) from two rocprofv3 --pmc passes.
 
-usage: traffic_json.py <dir with pmc_fetch/ and pmc_write/> <out.json>
+usage: traffic_json.py <dir with pmc_fetch/ and pmc_write/> <out.json> [<dir with pmc_ea/ from scripts/pmc_l2.sh>]
 FETCH_SIZE and WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE tallies 128-byte read requests as 64 bytes,
 so the read side is doubled (verified here on k_setup, whose reads are a known 37 bytes per triangle);
 for kernels whose reads are scattered 64-byte records the doubled figure is an upper bound.
@@ -26,5 +26,14 @@ res = {"_note": "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; _raw h
 for k in sorted(set(fetch) | set(write)):
     if k.startswith("k_"):
         res["k_ascii" if k.startswith("k_ascii") else k] = int((2.0 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024)
+if len(sys.argv) > 3:
+    rd = per_kernel(sys.argv[3] + "/pmc_ea", "TCC_EA0_RDREQ_sum")
+    req = {}
+    for k, v in sorted(rd.items()):
+        if k.startswith("k_"):
+            req["k_ascii" if k.startswith("k_ascii") else k] = int(v)
+    res["_read_requests"] = req
+    res["_read_requests_note"] = ("memory-side read requests per launch (TCC_EA0_RDREQ_sum); the scattered-read ceiling "
+                                  "measured by scripts/micro/fetch_granularity.hip is 36e9 lines/s")
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k.startswith("k_")}))
