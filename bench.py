@@ -22,6 +22,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E peak
 SCATTERED_LINES_G_PER_S = 36.0  # 128-byte lines per second (1e9) for scattered reads, scripts/micro/fetch_granularity.hip (profiles/r01f_fetch_granularity.txt)
+N_SIMDS = 256 * 4            # compute units x SIMDs
+PEAK_CLOCK_HZ = 2.4e9        # peak engine clock
 N_TRIS = 1_000_000
 COLS, ROWS = 1920, 1080
 
@@ -185,12 +187,14 @@ def main():
         dom_s = kern_serial[dom] * 1e-6
         achieved = per_launch_bytes.get(dom, 0) / dom_s / 1e9
         traffic = requests = None
+        valu = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
             traffic = tj.get(dom)
             requests = tj.get("_read_requests", {}).get(dom)
+            valu = tj.get("_valu_instructions", {})
         line = {
             "metric": "frames/sec at 1920x1080 cell grid, 1M tris", "value": fps, "unit": "frames/s",
             "mtri_per_s": fps * args.tris / 1e6,
@@ -209,7 +213,13 @@ def main():
                          # duration, next to the scattered-line rate a microbenchmark reaches on this chip
                          "read_requests": requests,
                          "read_request_rate_G_per_s": (requests / dom_s / 1e9) if requests else None,
-                         "scattered_line_ceiling_G_per_s": SCATTERED_LINES_G_PER_S},
+                         "scattered_line_ceiling_G_per_s": SCATTERED_LINES_G_PER_S,
+                         # what the kernel is bound by in fact: vector-ALU issue.  Wave instructions per launch (PMC) x 4
+                         # cycles over the SIMD-cycles of the live duration at the peak clock
+                         "valu_instructions": valu.get(dom),
+                         "valu_busy_frac": (valu[dom] * 4.0 / (N_SIMDS * PEAK_CLOCK_HZ * dom_s)) if (valu.get(dom) and not gather) else None},
+            # the same for the whole frame at the measured frame rate (kernels of three frames share the chip)
+            "frame_valu_busy_frac": (sum(valu.get(k, 0) for k in kern_serial) * 4.0 * fps / (N_SIMDS * PEAK_CLOCK_HZ)) if (valu and not gather) else None,  # (counters are of whole frames on one GPU)
             "gather_verified": gather_ok,
             "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
             "kernels_avg_us_serial": {k: round(v, 2) for k, v in kern_serial.items()},

@@ -35,5 +35,9 @@ if len(sys.argv) > 3:
     res["_read_requests"] = req
     res["_read_requests_note"] = ("memory-side read requests per launch (TCC_EA0_RDREQ_sum); the scattered-read ceiling "
                                   "measured by scripts/micro/fetch_granularity.hip is 36e9 lines/s")
+valu = per_kernel(src + "/pmc_inst", "SQ_INSTS_VALU")  # (present when the directory comes from scripts/profile_round.sh)
+if valu:
+    res["_valu_instructions"] = {("k_ascii" if k.startswith("k_ascii") else k): int(v) for k, v in sorted(valu.items()) if k.startswith("k_")}
+    res["_valu_instructions_note"] = "wave-level vector instructions per launch (SQ_INSTS_VALU); one occupies a SIMD for four cycles"
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k.startswith("k_")}))
