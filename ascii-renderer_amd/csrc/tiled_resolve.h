@@ -162,9 +162,11 @@ __device__ __forceinline__ void raster_range(const FrameParams &fp, const Edges 
     for (int k = 0; k < 3; k++)
         thr[k] = (ed.a[k] > 0.0 || (ed.a[k] == 0.0 && ed.b[k] > 0.0)) ? 0.0 : 4.9406564584124654e-324;
     const float apx[3] = {fabsf(a32[0]) * float(i1 + 1), fabsf(a32[1]) * float(i1 + 1), fabsf(a32[2]) * float(i1 + 1)};
+    // a chunk's candidate mask gives each row 2^ls bits, the next power of two >= the width (<= 64: a tile's): bit
+    // k is row k >> ls, column k & (2^ls - 1)
     const int w = i1 - i0 + 1;
-    const int rows_per_chunk = max(1, 64 / w);
-    const float inv_w = 1.0f / float(w);
+    const int ls = w <= 1 ? 0 : 32 - __clz(w - 1);
+    const int rows_per_chunk = 64 >> ls;
     const float flo = float(i0), fhi = float(i1);
     for (int rc = r0; rc <= r1; rc += rows_per_chunk) {
         const int rc1 = min(rc + rows_per_chunk - 1, r1);
@@ -185,15 +187,14 @@ __device__ __forceinline__ void raster_range(const FrameParams &fp, const Edges 
             const int n = ihi - ilo + 1;
             if (n <= 0) continue;
             const unsigned long long run = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
-            cand |= run << ((rr - rc) * w + (ilo - i0));
+            cand |= run << (((rr - rc) << ls) + (ilo - i0));
         }
         uint32_t clo = uint32_t(cand), chi = uint32_t(cand >> 32);
         while (clo | chi) {
             int k;
             if (clo) { k = __ffs(int(clo)) - 1; clo &= clo - 1u; }
             else { k = 31 + __ffs(int(chi)); chi &= chi - 1u; }
-            const int dr = int((float(k) + 0.5f) * inv_w);  // k / w, exact for k < 64
-            const int rr = rc + dr, i = i0 + (k - dr * w);
+            const int rr = rc + (k >> ls), i = i0 + (k & ((1 << ls) - 1));
             const double px = double(i) + 0.5, py = double(fp.rows - 1 - rr) + 0.5;
             const double E0 = ed.a[0] * px + (ed.b[0] * py + ed.c[0]);
             const double E1 = ed.a[1] * px + (ed.b[1] * py + ed.c[1]);
