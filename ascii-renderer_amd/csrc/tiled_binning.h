@@ -421,10 +421,10 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Tr
         base[b] = before + dircount[size_t(blockIdx.x) * nbins + b];
     }
     __syncthreads();
-    // exclusive scan of the totals over the bins: each lane takes a run of consecutive bins
-    constexpr int kRun = kMaxBins / kSetupThreads;
+    // exclusive scan of the totals over the bins: each lane takes a run of consecutive bins (one bin per lane up
+    // to 256 bins, which covers 1080p)
+    const int kRun = (nbins + kSetupThreads - 1) / kSetupThreads;  // <= kMaxBins / kSetupThreads
     uint32_t run_total = 0;
-#pragma unroll
     for (int q = 0; q < kRun; q++) {
         const int b = int(tid) * kRun + q;
         run_total += b < nbins ? cnt[b] : 0u;
@@ -432,7 +432,6 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Tr
     uint32_t n_entries;
     uint32_t start = block_exclusive_scan<kSetupThreads / 64>(run_total, s_wave, n_entries);
     bool overflow = false;
-#pragma unroll
     for (int q = 0; q < kRun; q++) {
         const int b = int(tid) * kRun + q;
         if (b >= nbins) break;
