@@ -360,23 +360,61 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
         uint8_t px[4];
         shade_from_triangle<TEX>(fp, vbo, idx, triattr, triuv, atlas, ts, id, (low & 1u) != 0u, i, fp.rows - 1 - rr, px);
         if (fp.want_ids) ids[size_t(rr) * fp.cols + i] = id;
+        // untextured frames have alpha 255 everywhere: the byte carries the cell's ramp index to the output step
+        // instead, which then has no arithmetic left to do per cell
+        const uint32_t top = TEX ? uint32_t(px[3]) : uint32_t(ramp_index(int(px[0]), int(px[1]), int(px[2]), fp.ramp_len));
         keys[c] = (keys[c] & 0xFFFFFFFF00000000ull) |  // (the depth the raster pass computed for this winner stays)
-                  (uint32_t(px[0]) | (uint32_t(px[1]) << 8) | (uint32_t(px[2]) << 16) | (uint32_t(px[3]) << 24));
+                  (uint32_t(px[0]) | (uint32_t(px[1]) << 8) | (uint32_t(px[2]) << 16) | (top << 24));
     }
     __syncthreads();
 
-    // the tile's rows: 64 consecutive cells per row segment
+    // colour and ramp index of a resolved key (a shaded cell always has depth < 1.0 in the high word)
+    auto decode = [&](uint64_t k, uint32_t &col, int &ri) {
+        const bool bg = k == kBackgroundKey;
+        if (TEX) {
+            col = bg ? 0xFF000000u : uint32_t(k);
+            ri = ramp_index(int(col & 255u), int((col >> 8) & 255u), int((col >> 16) & 255u), fp.ramp_len);
+        } else {
+            col = bg ? 0xFF000000u : (uint32_t(k) | 0xFF000000u);
+            ri = bg ? 0 : int(uint32_t(k) >> 24);  // (black is ramp index 0)
+        }
+        return bg;
+    };
+    // the tile's rows.  Usual case: a lane writes four consecutive cells of a row, one 16-byte store each for colour
+    // and depth and one dword of ramp indices (rows and the tile's columns start at multiples of four cells)
+    if ((fp.cols & 3) == 0 && fp.mode_on && !fp.want_ids) {
+        for (int q = int(tid); q < kTileCells / 4; q += 256) {
+            const int row = q >> 4, x = (q & 15) * 4;
+            const int rr = tr0 + row, i = tx0 + x;
+            if (i > tx1 || rr > tr1) continue;  // (a group of four lies inside or outside the grid as a whole)
+            const size_t cell = size_t(rr) * fp.cols + i;
+            uint32_t col[4], ri4 = 0;
+            float d[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint64_t key = keys[row * kTileW + x + k];
+                int ri;
+                const bool bg = decode(key, col[k], ri);
+                d[k] = bg ? 1.0f : __uint_as_float(uint32_t(key >> 32));
+                ri4 |= uint32_t(ri) << (8 * k);
+            }
+            reinterpret_cast<uint4 *>(rgba)[cell >> 2] = make_uint4(col[0], col[1], col[2], col[3]);
+            reinterpret_cast<float4 *>(depth)[cell >> 2] = make_float4(d[0], d[1], d[2], d[3]);
+            reinterpret_cast<uint32_t *>(ridx)[cell >> 2] = ri4;
+        }
+        return;
+    }
     for (int c = int(tid); c < kTileCells; c += 256) {
         const int rr = tr0 + (c >> 6), i = tx0 + (c & 63);
         if (i > tx1 || rr > tr1) continue;
         const size_t cell = size_t(rr) * fp.cols + i;
         const uint64_t k = keys[c];
-        const bool bg = k == kBackgroundKey;  // a shaded cell always has depth < 1.0 in the high word
-        const uint32_t col = bg ? 0xFF000000u : uint32_t(k);
+        uint32_t col;
+        int ri;
+        const bool bg = decode(k, col, ri);
         reinterpret_cast<uint32_t *>(rgba)[cell] = col;
         depth[cell] = bg ? 1.0f : __uint_as_float(uint32_t(k >> 32));
         if (fp.want_ids && bg) ids[cell] = 0xFFFFFFFFu;
-        const int ri = ramp_index(int(col & 255u), int((col >> 8) & 255u), int((col >> 16) & 255u), fp.ramp_len);
         if (fp.mode_on) ridx[cell] = uint8_t(ri);
         else if (rr >= fp.row0 && rr < fp.row1) {
             const uint32_t qa = col >> 24;  // 255 unless an atlas texel put an ASCII override there
