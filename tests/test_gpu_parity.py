@@ -131,6 +131,25 @@ def test_near_plane_and_huge_triangles(pkg, oracle, R):
                 assert c["bin_records"] > 0 and c["pool_overflow"] == 0
 
 
+def test_projection_scaled_by_powers_of_two(pkg, oracle, R):
+    """Clip coordinates scaled far up and down (w around 2^-104 .. 2^104): the cell ranges leave the reciprocal's
+    safe interval and take the division, edge values under- and overflow binary32 - whatever comes out, the HIP
+    path and the oracle follow the same arithmetic."""
+    rng = np.random.default_rng(21)
+    T = 600
+    centre = rng.uniform(-6, 6, size=(T, 1, 3))
+    P = (centre + rng.uniform(-1, 1, size=(T, 3, 3)) * rng.choice([0.05, 0.5, 4.0], size=(T, 1, 1))).reshape(-1, 3)
+    vbo, idx = pkg.host.mesh_to_vbo(P.astype(np.float32), np.arange(T * 3).reshape(-1, 3), rng.uniform(0, 1, size=(T, 3)))
+    proj, view = pkg.host.camera_matrices({"pos": (0.1, 0.2, 0.3), "yaw": 0.7, "pitch": -0.2}, 160, 90, 0.5)
+    covered = {}
+    for k in (0, -30, 30, -104, 104):
+        sc = {"name": "scaled", "vbo": vbo, "idx": idx, "proj": (np.asarray(proj, dtype=np.float32) * np.float32(2.0 ** k)),
+              "view": view, "lights": pkg.host.pack_lights({}), "cols": 160, "rows": 90}
+        out, ids = _check(pkg, oracle, R, sc, label="projection x 2^%d" % k)
+        covered[k] = int(np.count_nonzero(ids != 0xFFFFFFFF))
+    assert covered[0] > 1000 and covered[-30] == covered[0] and covered[30] == covered[0]
+
+
 def _textured_case(golden_dir, pkg, name):
     with open(os.path.join(golden_dir, "ref_pathtrace_uv.json")) as fh:
         case = next(c for c in json.load(fh)["cases"] if c["name"] == name)
