@@ -73,7 +73,7 @@ __device__ __forceinline__ void shade_clipped_record(const FrameParams &fp, cons
     shade(fp, v, px);
 }
 
-// Colour and depth of cell (i, j) from the winner's triangle record: its setup is redone (same expressions as
+// Colour of cell (i, j) from the winner's triangle record: its setup is redone (same expressions as
 // k_setup, so the same values), then a flat triangle takes normal and colour from the record itself, any other
 // from its attribute row; world positions (point lights) are the record's.  Clipped sub-triangles go through
 // shade_clipped_record.
@@ -137,7 +137,7 @@ __device__ __forceinline__ void shade_from_triangle(const FrameParams &fp, const
     shade(fp, v, px);
 }
 
-// Scans rows [r0, r1] x columns [i0, i1] (at most 64 columns) of one record into the LDS key tile.
+// Scans rows [r0, r1] x columns [i0, i1] (at most 64 columns) of one sub-triangle into the LDS key tile.
 // Most cells of a cell range lie outside the triangle, and lanes of a wavefront walk ranges of very
 // different sizes, so the scan is split in two: (1) per row, each edge function is evaluated in
 // binary32 and solved for the column where it crosses a conservative error band, which gives the
@@ -291,8 +291,8 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
                 raster_range(fp, ed, tile_key_low(id, clipped), i0, i1, r0, r1, tx0, tr0, keys);
             }
             __syncthreads();
-            // sweep list: the records are brought into LDS 64 at a time (one fetch latency per batch instead of
-            // one per record), then every wavefront sweeps a record of its own, 64 cells per step
+            // sweep list: the triangle records are brought into LDS 64 at a time (one fetch latency per batch instead
+            // of one per triangle), then every wavefront sweeps a triangle of its own, 64 cells per step
             const uint32_t nb = min(n_big, uint32_t(kTileBigMax));
             TriStatic *stage = reinterpret_cast<TriStatic *>(covered);  // (the cell list is not in use before the raster step ends)
             for (uint32_t b0 = 0; b0 < nb; b0 += kTileStage) {
