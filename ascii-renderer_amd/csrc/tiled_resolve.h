@@ -176,7 +176,7 @@ __device__ __forceinline__ void raster_range(const FrameParams &fp, const Edges 
             float lo = flo, hi = fhi;  // candidate columns, as cell indices
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const float r32 = float(ed.b[k] * py + ed.c[k]);
+                const float r32 = float(__builtin_fma(ed.b[k], py, ed.c[k]));  // (fused: closer to b py + c than the bound assumes)
                 const float band = kBand * (apx[k] + fabsf(r32));
                 const float x = (-band - r32) * inv_a[k] - 0.5f;  // crossing column as a cell index
                 lo = fmaxf(lo, a32[k] > 0.0f ? x : flo);
