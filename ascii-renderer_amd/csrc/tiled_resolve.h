@@ -161,7 +161,9 @@ __device__ __forceinline__ void raster_range(const FrameParams &fp, const Edges 
 #pragma unroll
     for (int k = 0; k < 3; k++)
         thr[k] = (ed.a[k] > 0.0 || (ed.a[k] == 0.0 && ed.b[k] > 0.0)) ? 0.0 : 4.9406564584124654e-324;
-    const float apx[3] = {fabsf(a32[0]) * float(i1 + 1), fabsf(a32[1]) * float(i1 + 1), fabsf(a32[2]) * float(i1 + 1)};
+    // (the band's |a32| px_max term, already times 2^-18: a power of two, so scaling first changes nothing)
+    const float apx[3] = {kBand * (fabsf(a32[0]) * float(i1 + 1)), kBand * (fabsf(a32[1]) * float(i1 + 1)),
+                          kBand * (fabsf(a32[2]) * float(i1 + 1))};
     // a chunk's candidate mask gives each row 2^ls bits, the next power of two >= the width (<= 64: a tile's): bit
     // k is row k >> ls, column k & (2^ls - 1)
     const int w = i1 - i0 + 1;
@@ -177,8 +179,8 @@ __device__ __forceinline__ void raster_range(const FrameParams &fp, const Edges 
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const float r32 = float(__builtin_fma(ed.b[k], py, ed.c[k]));  // (fused: closer to b py + c than the bound assumes)
-                const float band = kBand * (apx[k] + fabsf(r32));
-                const float x = (-band - r32) * inv_a[k] - 0.5f;  // crossing column as a cell index
+                const float band = __builtin_fmaf(kBand, fabsf(r32), apx[k]);
+                const float x = __builtin_fmaf(-band - r32, inv_a[k], -0.5f);  // crossing column as a cell index (fused: nearer the true crossing)
                 lo = fmaxf(lo, a32[k] > 0.0f ? x : flo);
                 hi = fminf(hi, a32[k] < 0.0f ? x : fhi);
             }
