@@ -96,17 +96,6 @@ __device__ __forceinline__ void shade_from_triangle(const FrameParams &fp, const
         to_screen_valid(in0.c, in1.c, in2.c, fp.hw, fp.hh, sc);
     }
     const uint32_t t = id >> 1;
-    float4 a0, a1, a2;
-    float2 c0, c1, c2;
-    if (ts.flags & kFlagFlat) {
-        a0 = a1 = a2 = make_float4(ts.n[0], ts.n[1], ts.n[2], ts.c[0]);
-        c0 = c1 = c2 = make_float2(ts.c[1], ts.c[2]);
-    } else {
-        const float4 *row = reinterpret_cast<const float4 *>(triattr) + size_t(t) * 6;
-        a0 = row[0]; a1 = row[2]; a2 = row[4];
-        c0 = *reinterpret_cast<const float2 *>(row + 1); c1 = *reinterpret_cast<const float2 *>(row + 3);
-        c2 = *reinterpret_cast<const float2 *>(row + 5);
-    }
     Edges e;
     edges_from_screen(sc, e);
     const double pxd = double(i) + 0.5, pyd = double(j) + 0.5;  // (the cell is covered and its depth is the key's: no test here)
@@ -116,12 +105,25 @@ __device__ __forceinline__ void shade_from_triangle(const FrameParams &fp, const
     const float rS = 1.0f / ((f[0] + f[1]) + f[2]);
     const float b0 = f[0] * rS, b1 = f[1] * rS, b2 = f[2] * rS;
     float v[9];
-    v[3] = (b0 * a0.x + b1 * a1.x) + b2 * a2.x;
-    v[4] = (b0 * a0.y + b1 * a1.y) + b2 * a2.y;
-    v[5] = (b0 * a0.z + b1 * a1.z) + b2 * a2.z;
-    v[6] = (b0 * a0.w + b1 * a1.w) + b2 * a2.w;
-    v[7] = (b0 * c0.x + b1 * c1.x) + b2 * c2.x;
-    v[8] = (b0 * c0.y + b1 * c1.y) + b2 * c2.y;
+    if (ts.flags & kFlagFlat) {
+        // the same three-term sum as for a smooth triangle, with one value at all three vertices
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            v[3 + q] = (b0 * ts.n[q] + b1 * ts.n[q]) + b2 * ts.n[q];
+            v[6 + q] = (b0 * ts.c[q] + b1 * ts.c[q]) + b2 * ts.c[q];
+        }
+    } else {
+        const float4 *row = reinterpret_cast<const float4 *>(triattr) + size_t(t) * 6;
+        const float4 a0 = row[0], a1 = row[2], a2 = row[4];
+        const float2 c0 = *reinterpret_cast<const float2 *>(row + 1), c1 = *reinterpret_cast<const float2 *>(row + 3),
+                     c2 = *reinterpret_cast<const float2 *>(row + 5);
+        v[3] = (b0 * a0.x + b1 * a1.x) + b2 * a2.x;
+        v[4] = (b0 * a0.y + b1 * a1.y) + b2 * a2.y;
+        v[5] = (b0 * a0.z + b1 * a1.z) + b2 * a2.z;
+        v[6] = (b0 * a0.w + b1 * a1.w) + b2 * a2.w;
+        v[7] = (b0 * c0.x + b1 * c1.x) + b2 * c2.x;
+        v[8] = (b0 * c0.y + b1 * c1.y) + b2 * c2.y;
+    }
     if (fp.n_pl > 0) {
 #pragma unroll
         for (int q = 0; q < 3; q++) v[q] = (b0 * ts.p[q] + b1 * ts.p[3 + q]) + b2 * ts.p[6 + q];
