@@ -48,6 +48,18 @@ struct TriRec {
     uint32_t pad;
 };
 
+// The frame parameters where the launch put them: the kernel-argument segment, of which FrameParams is the first
+// member in every kernel that calls this.  The compiler otherwise loads every field a kernel uses once, at its top,
+// and keeps it in a scalar register to the end - more than there are, so they are parked in lanes of a vector
+// register and fetched back with a vector instruction at each use.  Reading a late phase's constants through this
+// pointer - opaque to the optimiser, so the loads stay where they are written - costs scalar loads instead.
+using KernargFrameParams = const __attribute__((address_space(4))) FrameParams;
+__device__ __forceinline__ KernargFrameParams *kernarg_params() {
+    KernargFrameParams *q = (KernargFrameParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));
+    return q;
+}
+
 template <int NV>
 struct Vert {
     float c[4];                // clip x, y, z, w

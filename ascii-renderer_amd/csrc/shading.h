@@ -10,7 +10,9 @@ __device__ __forceinline__ int ramp_index(int r, int g, int b, int ramp_len) {
 }
 
 // raster_shader.js:42-62 in binary32.
-__device__ __forceinline__ void shade(const FrameParams &fp, const float *v, uint8_t (&out)[4]) {
+// FP: FrameParams, or the same struct read in place from the kernel-argument segment (kernarg_params).
+template <typename FP>
+__device__ __forceinline__ void shade(const FP &fp, const float *v, uint8_t (&out)[4]) {
     const float len2 = (v[3] * v[3] + v[4] * v[4]) + v[5] * v[5];
     const float inv = (len2 > 0.0f) ? 1.0f / sqrtf(len2) : 0.0f;
     const float N[3] = {v[3] * inv, v[4] * inv, v[5] * inv};

@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256) void k_uvflags(const uint4 *__restrict__ triuv
     tri[t].flags = (tri[t].flags & ~kFlagTextured) | (sample ? kFlagTextured : 0u);
 }
 
-__device__ __forceinline__ Vert<0> transform_position(const FrameParams &fp, float x, float y, float z) {
+template <typename FP>
+__device__ __forceinline__ Vert<0> transform_position(const FP &fp, float x, float y, float z) {
     Vert<0> o;
 #pragma unroll
     for (int r = 0; r < 4; r++)

@@ -77,8 +77,8 @@ __device__ __forceinline__ void shade_clipped_record(const FrameParams &fp, cons
 // k_setup, so the same values), then a flat triangle takes normal and colour from the record itself, any other
 // from its attribute row; world positions (point lights) are the record's.  Clipped sub-triangles go through
 // shade_clipped_record.
-template <bool TEX>
-__device__ __forceinline__ void shade_from_triangle(const FrameParams &fp, const float *__restrict__ vbo,
+template <bool TEX, typename FP>
+__device__ __forceinline__ void shade_from_triangle(const FrameParams &fp, const FP &kp, const float *__restrict__ vbo,
                                                     const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
                                                     const uint4 *__restrict__ triuv, const uint32_t *__restrict__ atlas,
                                                     const TriStatic &ts, uint32_t id, bool clipped, int i, int j,
@@ -91,9 +91,9 @@ __device__ __forceinline__ void shade_from_triangle(const FrameParams &fp, const
         return;
     }
     {   // (clip-space z is not needed: the depth is the key's)
-        const Vert<0> in0 = transform_position(fp, ts.p[0], ts.p[1], ts.p[2]), in1 = transform_position(fp, ts.p[3], ts.p[4], ts.p[5]),
-                      in2 = transform_position(fp, ts.p[6], ts.p[7], ts.p[8]);
-        to_screen_valid(in0.c, in1.c, in2.c, fp.hw, fp.hh, sc);
+        const Vert<0> in0 = transform_position(kp, ts.p[0], ts.p[1], ts.p[2]), in1 = transform_position(kp, ts.p[3], ts.p[4], ts.p[5]),
+                      in2 = transform_position(kp, ts.p[6], ts.p[7], ts.p[8]);
+        to_screen_valid(in0.c, in1.c, in2.c, kp.hw, kp.hh, sc);
     }
     const uint32_t t = id >> 1;
     Edges e;
@@ -124,7 +124,7 @@ __device__ __forceinline__ void shade_from_triangle(const FrameParams &fp, const
         v[7] = (b0 * c0.x + b1 * c1.x) + b2 * c2.x;
         v[8] = (b0 * c0.y + b1 * c1.y) + b2 * c2.y;
     }
-    if (fp.n_pl > 0) {
+    if (kp.n_pl > 0) {
 #pragma unroll
         for (int q = 0; q < 3; q++) v[q] = (b0 * ts.p[q] + b1 * ts.p[3 + q]) + b2 * ts.p[6 + q];
     } else {
@@ -136,7 +136,7 @@ __device__ __forceinline__ void shade_from_triangle(const FrameParams &fp, const
         const float tv = (b0 * float(uv.x >> 16) + b1 * float(uv.y >> 16)) + b2 * float(uv.z >> 16);
         if (apply_texture(fp, atlas, tu, tv, v + 6, px)) return;
     }
-    shade(fp, v, px);
+    shade(kp, v, px);
 }
 
 // Scans rows [r0, r1] x columns [i0, i1] (at most 64 columns) of one sub-triangle into the LDS key tile.
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
         const uint32_t id = low >> 1;
         const TriStatic ts = tri[id >> 1];
         uint8_t px[4];
-        shade_from_triangle<TEX>(fp, vbo, idx, triattr, triuv, atlas, ts, id, (low & 1u) != 0u, i, fp.rows - 1 - rr, px);
+        shade_from_triangle<TEX>(fp, *kernarg_params(), vbo, idx, triattr, triuv, atlas, ts, id, (low & 1u) != 0u, i, fp.rows - 1 - rr, px);
         if (fp.want_ids) ids[size_t(rr) * fp.cols + i] = id;
         // untextured frames have alpha 255 everywhere: the byte carries the cell's ramp index to the output step
         // instead, which then has no arithmetic left to do per cell
