@@ -53,8 +53,6 @@ struct TriRec {
 // and keeps it in a scalar register to the end - more than there are, so they are parked in lanes of a vector
 // register and fetched back with a vector instruction at each use.  Reading a late phase's constants through this
 // pointer - opaque to the optimiser, so the loads stay where they are written - costs scalar loads instead.
-using float2v = __attribute__((ext_vector_type(2))) float;  // maps onto the packed binary32 instructions
-
 using KernargFrameParams = const __attribute__((address_space(4))) FrameParams;
 __device__ __forceinline__ KernargFrameParams *kernarg_params() {
     KernargFrameParams *q = (KernargFrameParams *)__builtin_amdgcn_kernarg_segment_ptr();

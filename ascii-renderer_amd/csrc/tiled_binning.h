@@ -223,21 +223,6 @@ __device__ __forceinline__ Vert<0> transform_position(const FP &fp, float x, flo
     return o;
 }
 
-// The same on two-component vectors - clip (x, y) and (z, w) - so that each step is one packed instruction on a
-// register pair that is already in place (left to itself the compiler pairs values of different vertices and moves
-// them together first); per component the operations and their order are unchanged.  For k_setup, which it makes
-// 3 % faster; the tile resolve is 4 % slower with it although it executes fewer instructions, and keeps the above.
-template <typename FP>
-__device__ __forceinline__ Vert<0> transform_position_packed(const FP &fp, float x, float y, float z) {
-    const float2v xy = ((float2v{fp.pv[0], fp.pv[1]} * x + float2v{fp.pv[4], fp.pv[5]} * y) + float2v{fp.pv[8], fp.pv[9]} * z) +
-                       float2v{fp.pv[12], fp.pv[13]};
-    const float2v zw = ((float2v{fp.pv[2], fp.pv[3]} * x + float2v{fp.pv[6], fp.pv[7]} * y) + float2v{fp.pv[10], fp.pv[11]} * z) +
-                       float2v{fp.pv[14], fp.pv[15]};
-    Vert<0> o;
-    o.c[0] = xy.x; o.c[1] = xy.y; o.c[2] = zw.x; o.c[3] = zw.y;
-    return o;
-}
-
 // Range of bins a cell range touches.
 __device__ __forceinline__ void bin_range(const FrameParams &fp, int i0, int i1, int j0, int j1, int &bx0, int &bx1,
                                           int &by0, int &by1) {
@@ -256,8 +241,8 @@ struct Candidate {
 // plane cut the triangle.
 __device__ __forceinline__ void triangle_setup(const FrameParams &fp, const float (&p)[9], int jlo, int jhi,
                                                Candidate (&c)[2], bool (&have)[2], bool &clipped) {
-    const Vert<0> in0 = transform_position_packed(fp, p[0], p[1], p[2]), in1 = transform_position_packed(fp, p[3], p[4], p[5]),
-                  in2 = transform_position_packed(fp, p[6], p[7], p[8]);
+    const Vert<0> in0 = transform_position(fp, p[0], p[1], p[2]), in1 = transform_position(fp, p[3], p[4], p[5]),
+                  in2 = transform_position(fp, p[6], p[7], p[8]);
     Vert<0> s0[3], s1[3];
     const int ns = clip_near<0>(in0, in1, in2, s0, s1);
     clipped = ns == 2 || (in0.c[2] + in0.c[3] < 0.0f) || (in1.c[2] + in1.c[3] < 0.0f) || (in2.c[2] + in2.c[3] < 0.0f);
