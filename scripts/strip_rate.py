@@ -4,6 +4,8 @@ import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ar = importlib.import_module("ascii-renderer_amd")
 mg = importlib.import_module("ascii-renderer_amd.multigpu")
+if os.environ.get("AR_LIB"):
+    ar.binding.LIB_PATH = os.environ["AR_LIB"]
 cols, rows = 1920, 1080
 sc = ar.scenes.random_scene(1_000_000, cols, rows)
 R = ar.Renderer(0)
