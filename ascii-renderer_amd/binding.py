@@ -238,6 +238,21 @@ class Renderer:
             raise ValueError("proj and view must have 16 elements")
         self._check(self._L.ar_set_camera(self._h, pp, vp))
 
+    @staticmethod
+    def prepare_camera(proj, view):
+        """The two matrices as ready-made C arrays for set_camera_prepared (a per-frame camera without per-frame
+        conversions on the host)."""
+        p = np.ascontiguousarray(proj, dtype=np.float32).reshape(-1)
+        v = np.ascontiguousarray(view, dtype=np.float32).reshape(-1)
+        if p.size != 16 or v.size != 16:
+            raise ValueError("proj and view must have 16 elements")
+        return (ctypes.c_float * 16)(*p.tolist()), (ctypes.c_float * 16)(*v.tolist())
+
+    def set_camera_prepared(self, prepared):
+        rc = self._L.ar_set_camera(self._h, prepared[0], prepared[1])
+        if rc:
+            self._check(rc)
+
     def set_lights(self, lights):
         _a, ap = _f32(lights["ambient"])
         _d, dp = _f32(lights["dir"])

@@ -318,6 +318,8 @@ int ar_set_stream(ar_ctx *ctx, void *hip_stream) {
 int ar_set_ascii_target(ar_ctx *ctx, void *d_ascii, int first_row) {
     if (!ctx) return AR_E_ARG;
     if (first_row < 0) return fail(ctx, AR_E_ARG, "ar_set_ascii_target: bad first row %d", first_row);
+    // the smoothing kernel stores four codes at a time when the row length is a multiple of four
+    if (reinterpret_cast<uintptr_t>(d_ascii) & 3u) return fail(ctx, AR_E_ARG, "ar_set_ascii_target: the buffer must be 4-byte aligned");
     ctx->ascii_target = static_cast<uint8_t *>(d_ascii);
     ctx->target_row = d_ascii ? first_row : 0;
     return 0;
@@ -563,13 +565,20 @@ double js_round(double x) {
     return r;
 }
 
-// d_rgba (device, n cells) -> colors (host).  steps <= 0: the reference's max(3, max(2, ramp length)).
-int colors_from_device(ar_ctx *ctx, const uint8_t *d_rgba, size_t n, int steps, int grayscale, uint32_t *colors) {
+// steps <= 0: the reference's max(3, max(2, ramp length)) (js/renderer.js:13-19); else checked against 2..256.
+int resolve_color_steps(ar_ctx *ctx, int &steps) {
     if (steps <= 0) {
         const int rl = ctx->fp.ramp_len < 2 ? 2 : ctx->fp.ramp_len;
-        steps = rl < 3 ? 3 : rl;   // js/renderer.js:13-19
+        steps = rl < 3 ? 3 : rl;
     }
     if (steps < 2 || steps > 256) return fail(ctx, AR_E_ARG, "colour steps %d not in 2..256", steps);
+    return 0;
+}
+
+// d_rgba (device, n cells) -> colors (host).
+int colors_from_device(ar_ctx *ctx, const uint8_t *d_rgba, size_t n, int steps, int grayscale, uint32_t *colors) {
+    int rs = resolve_color_steps(ctx, steps);
+    if (rs) return rs;
     if (grayscale) {  // black text everywhere (renderer.js:76-77)
         memset(colors, 0, n * sizeof(uint32_t));
         return 0;
@@ -599,6 +608,10 @@ int ar_quantize_colors(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, int
         return fail(ctx, AR_E_ARG, "ar_quantize_colors: bad arguments (%d x %d)", cols, rows);
     AR_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n = size_t(cols) * rows;
+    // the cases that need no device work return before anything of the caller's is handed to the copy engine
+    int rc = resolve_color_steps(ctx, steps);
+    if (rc) return rc;
+    if (grayscale) return colors_from_device(ctx, nullptr, n, steps, grayscale, colors);
     if (n > ctx->q_cells) {
         AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii);
@@ -608,7 +621,9 @@ int ar_quantize_colors(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, int
         ctx->q_cells = n;
     }
     AR_HIP(ctx, hipMemcpyAsync(ctx->d_q_rgba, rgba, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    return colors_from_device(ctx, ctx->d_q_rgba, n, steps, grayscale, colors);
+    rc = colors_from_device(ctx, ctx->d_q_rgba, n, steps, grayscale, colors);
+    if (rc) (void)hipStreamSynchronize(ctx->stream);  // the copy of the caller's buffer must not outlive the call
+    return rc;
 }
 
 int ar_read_colors(ar_ctx *ctx, int steps, int grayscale, uint32_t *colors) {
@@ -682,7 +697,7 @@ int ar_set_option(ar_ctx *ctx, int option, long long value) {
             ctx->path = int(value);
             return 0;
         case AR_OPT_OVERLAP: {
-            if (value < 0 || value > 2) return fail(ctx, AR_E_ARG, "AR_OPT_OVERLAP takes 0, 1 or 2");
+            if (value != 0 && value != 1) return fail(ctx, AR_E_ARG, "AR_OPT_OVERLAP takes 0 or 1");
             int rc = sync_streams(ctx);
             if (rc) return rc;
             ctx->overlap = int(value);

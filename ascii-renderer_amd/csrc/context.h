@@ -18,7 +18,7 @@ struct ar_ctx {
     bool ext_stream = false;        // stream is the caller's: every kernel goes there, frames do not overlap
     uint8_t *ascii_target = nullptr;  // caller's device buffer for the ASCII plane (ar_set_ascii_target), else d_ascii
     int target_row = 0;               // frame row stored at ascii_target
-    int overlap = 2;                // 0: frames one after the other on `stream`; 1, 2: consecutive frames alternate streams
+    int overlap = 1;                // 0: frames one after the other on `stream`; 1: consecutive frames rotate over the frame streams
     hipEvent_t ev_out[kSets + 1] = {};  // outputs complete on each frame stream / on `stream` (ar_stream_wait_frame)
     hipEvent_t ev_ext = nullptr;    // a caller's stream has consumed the outputs (ar_frame_wait_stream)
     float *d_vbo = nullptr;

@@ -268,6 +268,10 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
             if ((ent[q] >> kEntryMaskShift) & bit) list[atomicAdd(&n_list, 1u)] = ent[q] & kEntryLocMask;
         __syncthreads();
         const uint32_t nl = n_list;
+        // every wavefront must have read n_list before any of them appends again (a wavefront that skips the
+        // raster block goes straight to the next step's appends): the flush decision below has to be the same
+        // in all of them, because the block contains barriers
+        __syncthreads();
         const bool last = eb + 256 * kFilterBatch >= e_end;
         if (nl + 256 * kFilterBatch > uint32_t(kTileListMax) || last) {
             // sub-triangles with a small cell range inside the tile: one lane each; others -> sweep list

@@ -4,16 +4,28 @@
   python bench.py --gpus N --steps K --warmup W
 
 A step is one frame of the hot path (clear, vertex transform + raster + z-resolve, shade, ASCII) over
-the synthetic workload "1M random triangles, 1920x1080 cells" with mesh, camera and lights already
-resident in HBM.  With N > 1 (one process per GPU, launched by torch.distributed.run) the frame is
-split into N horizontal strips, each rank renders its strip from its own replica of the mesh and the
-ASCII strips are combined by one RCCL all-gather per frame (total work fixed: "strong" scaling).
-Rank 0 prints ONE JSON line.
+the synthetic workload "1M random triangles, 1920x1080 cells" with mesh and lights already resident in
+HBM and the camera set anew for every frame (a small yaw jitter, as the reference reads its camera live
+per frame, js/render/backends/raster.js:284-286).  With N > 1 (one process per GPU) the frame is split
+into N horizontal strips, each rank renders its strip from its own replica of the mesh and the ASCII
+strips are combined by RCCL all-gathers (total work fixed: "strong" scaling).
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself: the
+parent - before it has touched the GPU in any way - runs `python -m torch.distributed.run` as a child
+process, relays rank 0's JSON line and exits with the child's status.
+
+Timing: W untimed warm-up frames, then rounds of exactly K frames, each round bracketed by a barrier and
+a full synchronisation and taken as the MAX over ranks; rounds are repeated until at least 0.25 s has been
+measured and the median round is reported (`rounds` in the line), so that a short K does not make the
+result a one-millisecond sample.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import importlib
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,6 +38,61 @@ N_SIMDS = 256 * 4            # compute units x SIMDs
 PEAK_CLOCK_HZ = 2.4e9        # peak engine clock
 N_TRIS = 1_000_000
 COLS, ROWS = 1920, 1080
+MIN_TIMED_S = 0.25           # rounds of --steps frames are repeated until this much has been measured
+MAX_ROUNDS = 400
+YAW_JITTER = 0.01            # radians either side of the workload's view direction
+N_CAMERAS = 64
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--tris", type=int, default=N_TRIS)
+    ap.add_argument("--cols", type=int, default=COLS)
+    ap.add_argument("--rows", type=int, default=ROWS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the latency / readback / per-frame-gather legs")
+    ap.add_argument("--gather-batch", type=int, default=16, help="frames per RCCL all-gather (multi-GPU runs)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="take the strip + all-gather path even with one rank (rehearsal of the multi-GPU loop on one GPU)")
+    ap.add_argument("--dry", action="store_true",
+                    help="launcher rehearsal without a GPU: the ranks meet over gloo, time nothing and print the line's skeleton")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """Starts `--gpus` ranks of this script under torch.distributed.run as a CHILD process and relays rank 0's
+    line.  Runs before this process has imported torch or made any HIP call (a process that has initialised the
+    GPU must neither exec nor be replaced), and returns the child's exit status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, cwd=ROOT)
+    out, _ = child.communicate()
+    line = None
+    for raw in out.decode("utf-8", "replace").splitlines():
+        s = raw.strip()
+        if s.startswith("{") and s.endswith("}"):
+            line = s
+        elif s:
+            print(raw, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif child.returncode == 0:
+        print("bench.py: the ranks exited without printing a result line", file=sys.stderr)
+        return 1
+    return child.returncode
 
 
 def cpu_baseline(ar, sc, budget_s=10.0):
@@ -45,19 +112,40 @@ def cpu_baseline(ar, sc, budget_s=10.0):
                       % (n, sc["idx"].size // 3, sc["cols"], sc["rows"], os.cpu_count() or 0)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--tris", type=int, default=N_TRIS)
-    ap.add_argument("--cols", type=int, default=COLS)
-    ap.add_argument("--rows", type=int, default=ROWS)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather-batch", type=int, default=16, help="frames per RCCL all-gather (multi-GPU runs)")
-    ap.add_argument("--force-gather", action="store_true",
-                    help="take the strip + all-gather path even with one rank (rehearsal of the multi-GPU loop on one GPU)")
-    args = ap.parse_args()
+def dry_run(args, world, rank):
+    """The launcher's rehearsal: rendezvous over gloo, one collective, the line's skeleton from rank 0."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        seen, top = dist.get_world_size(), float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen, top = 1, 1.0
+    if rank == 0:
+        print(json.dumps({"metric": "frames/sec at 1920x1080 cell grid, 1M tris", "value": None, "unit": "frames/s",
+                          "n_gpus": world, "ranks_seen": seen, "max_rank_plus_one": top, "steps": args.steps,
+                          "warmup": args.warmup, "dry": True}), flush=True)
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry:
+        return dry_run(args, world, rank)
 
     # stdout carries the one JSON line and nothing else: libraries that write to file descriptor 1 (RCCL prints a
     # version banner there when a communicator is created) are sent to stderr for the rest of the run
@@ -70,11 +158,6 @@ def main():
     import torch.distributed as dist
 
     ar = importlib.import_module("ascii-renderer_amd")
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -86,93 +169,161 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         except TypeError:                                  # older torch: no device_id argument
             dist.init_process_group("nccl", rank=rank, world_size=world)
+    ranks_seen = dist.get_world_size() if gather else 1
 
     mg = importlib.import_module("ascii-renderer_amd.multigpu")
+    host = importlib.import_module("ascii-renderer_amd.host")
     sc = ar.scenes.random_scene(args.tris, args.cols, args.rows)
     R = ar.Renderer(local_rank)
     ar.scenes.upload(R, sc)
+    # the frame's camera: the workload's, turned by a yaw within +-YAW_JITTER that changes every frame
+    cams = []
+    for k in range(N_CAMERAS):
+        cam = dict(sc["camera"])
+        cam["yaw"] = cam["yaw"] + YAW_JITTER * math.sin(2.0 * math.pi * k / N_CAMERAS)
+        cams.append(R.prepare_camera(*host.camera_matrices(cam, args.cols, args.rows, 1.0)))
+    frame_no = [0]
     row0, row1 = mg.strip_bounds(args.rows, world, rank)
+    ts = None
     if gather:
         R.set_strip(row0, row1)
         torch.cuda.set_stream(torch.cuda.Stream())         # a real stream handle (the default stream's is 0)
         ts = torch.cuda.current_stream().cuda_stream
+
+    def make_batcher(batch):
         # two rings in rotation: the gather of one waits (on its stream) for the frames that filled it while the next
         # frames already fill the other; frames wait for a gather only when they come back to its ring, by which
         # time it is long over: two stream-ordered hand-overs per batch, no host waits, no pipeline drain
-        batcher = mg.StripBatcher(row1 - row0, args.cols, max(1, args.gather_batch), "cuda",
-                                  before_gather=lambda: R.stream_wait_frame(ts), after_gather=lambda: R.frame_wait_stream(ts))
+        return mg.StripBatcher(row1 - row0, args.cols, max(1, batch), "cuda",
+                               before_gather=lambda: R.stream_wait_frame(ts), after_gather=lambda: R.frame_wait_stream(ts))
+
+    batcher = make_batcher(args.gather_batch) if gather else None
     R.render_async(args.cols, args.rows)
     R.sync()
     # Multi-GPU loop: frames overlap on the renderer's own streams (three in flight) and write their ASCII
     # strip straight into a slot of the batch ring; every --gather-batch frames ONE RCCL all-gather combines
-    # the ranks' rings.  Per frame the host only launches the frame's kernels.
+    # the ranks' rings.  Per frame the host sets the camera and launches the frame's kernels.
 
-    def step():
-        if not gather:
+    def step(b=None):
+        R.set_camera_prepared(cams[frame_no[0] % N_CAMERAS])
+        frame_no[0] += 1
+        if b is None:
             R.render_async(args.cols, args.rows)
         else:
-            R.set_ascii_target(batcher.slot_ptr(), row0)
+            R.set_ascii_target(b.slot_ptr(), row0)
             R.render_async(args.cols, args.rows)
-            batcher.advance()
+            b.advance()
 
-    def fence():
-        if gather:
-            batcher.flush()
+    def fence(b=None):
+        if b is not None:
+            b.flush()
         R.sync()
         torch.cuda.synchronize()
         if gather:
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed_round(n, b=None):
+        """n frames between two fences; seconds, the maximum over the ranks."""
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(b)
+        fence(b)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def measure(n, b=None):
+        """Rounds of n frames until MIN_TIMED_S has been measured (the count follows from the first round's
+        all-rank maximum, so every rank runs the same number); (median round seconds, rounds)."""
+        first = timed_round(n, b)
+        rounds = min(MAX_ROUNDS, max(1, int(math.ceil(MIN_TIMED_S / max(first, 1e-9)))))
+        dts = sorted([first] + [timed_round(n, b) for _ in range(rounds - 1)])
+        return dts[len(dts) // 2] if len(dts) % 2 else 0.5 * (dts[len(dts) // 2 - 1] + dts[len(dts) // 2]), len(dts)
+
     for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        step(batcher)
+    fence(batcher)
+    dt, rounds = measure(args.steps, batcher)
     fps = args.steps / dt
 
-    # per-kernel durations (HIP events on the renderer's stream) over a second pass of the same steps
-    R.set_profiling(True)
-    R.kernel_stats()
-    for _ in range(args.steps):
-        R.render_async(args.cols, args.rows)
-    stats = R.kernel_stats()
-    # and once more with the frames strictly one after the other (no overlap between the kernels of
-    # consecutive frames): each kernel's duration when it has the GPU to itself
-    R.set_option("overlap", 0)
-    for _ in range(args.steps):
-        R.render_async(args.cols, args.rows)
-    stats_serial = R.kernel_stats()
-    R.set_option("overlap", 2)
-    R.set_profiling(False)
-    counters = R.frame_counters()
-
+    extras = {}
     gather_ok = None
     if gather:
         # the gathered grid of the last frame must be the full frame: compare with this rank's own full render
         torch.cuda.synchronize()
         R.set_strip(0, 0)
         R.set_ascii_target(None)
+        R.set_camera_prepared(cams[(frame_no[0] - 1) % N_CAMERAS])
         full = torch.from_numpy(R.render(args.cols, args.rows)["ascii"]).cuda()
         gather_ok = bool(torch.equal(full, batcher.frame(batcher.gathered - 1)))
         if not gather_ok:
             print("rank %d: gathered ASCII grid differs from a full-frame render" % rank, file=sys.stderr, flush=True)
+        R.set_strip(row0, row1)
+        if not args.no_extras and args.gather_batch != 1:
+            # the same loop with one all-gather per frame
+            b1 = make_batcher(1)
+            for _ in range(args.warmup):
+                step(b1)
+            fence(b1)
+            dt1, _r = measure(args.steps, b1)
+            extras["fps_gather_every_frame"] = args.steps / dt1
+        R.set_ascii_target(None)
+
+    # per-kernel durations (HIP events on the renderer's streams) over a pass of plain frames
+    n_prof = min(args.steps, 300)
+    R.set_profiling(True)
+    R.kernel_stats()
+    for _ in range(n_prof):
+        step()
+    stats = R.kernel_stats()
+    # and once more with the frames strictly one after the other (no overlap between the kernels of
+    # consecutive frames): each kernel's duration when it has the GPU to itself
+    R.set_option("overlap", 0)
+    for _ in range(n_prof):
+        step()
+    stats_serial = R.kernel_stats()
+    R.set_profiling(False)
+    counters = R.frame_counters()
+    if not args.no_extras and rank == 0:
+        # latency of a frame: enqueue and wait, one frame at a time (no overlap)
+        n_lat = min(args.steps, 200)
+        R.sync()
+        t0 = time.perf_counter()
+        for _ in range(n_lat):
+            step()
+            R.sync()
+        extras["latency_ms_serial"] = 1e3 * (time.perf_counter() - t0) / n_lat
+    R.set_option("overlap", 1)
+    if not args.no_extras and rank == 0 and not gather:
+        # what a caller of the blocking entry point gets: ar_render with the RGBA and ASCII planes copied out
+        def readback(rgba, ascii_, n=30):
+            R.render_into(args.cols, args.rows, rgba=rgba, ascii=ascii_)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                R.set_camera_prepared(cams[frame_no[0] % N_CAMERAS])
+                frame_no[0] += 1
+                R.render_into(args.cols, args.rows, rgba=rgba, ascii=ascii_)
+            return n / (time.perf_counter() - t0)
+        extras["readback_fps"] = {
+            "pageable_rgba_ascii": readback(np.zeros((args.rows, args.cols, 4), np.uint8), np.zeros((args.rows, args.cols), np.uint8)),
+            "pinned_rgba_ascii": readback(R.host_array((args.rows, args.cols, 4), np.uint8), R.host_array((args.rows, args.cols), np.uint8)),
+            "pinned_ascii_only": readback(None, R.host_array((args.rows, args.cols), np.uint8)),
+        }
+
     if rank == 0:
         cells = args.cols * (row1 - row0)
+        entries = counters["bin_records"]
         per_launch_bytes = {                             # algorithmic bytes one launch must move
             # tiled path: per-frame triangle stream is the derived position planes (36 B);
             # per cell RGBA8 4 + depth 4 + ramp index 1 written once, visibility keys stay in LDS
             "k_setup": args.tris * 36,
             "k_tile": cells * 9,
             "k_ascii": cells * 2,                        # ramp index in, ASCII code out
-            "k_fill": counters["bin_records"] * 4,       # one 4-byte entry per (sub-triangle, bin)
+            "k_fill": entries * 4,                       # one 4-byte entry per (sub-triangle, bin)
             "k_binscan": 0,                                # bookkeeping: no algorithmic traffic of its own
             # direct path: reference layout, 3 x 36 B vertices + 12 B indices per triangle
             "k_raster": args.tris * 120,
@@ -187,7 +338,7 @@ def main():
         dom_s = kern_serial[dom] * 1e-6
         achieved = per_launch_bytes.get(dom, 0) / dom_s / 1e9
         traffic = requests = None
-        valu = {}
+        valu, tj = {}, {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
@@ -195,17 +346,27 @@ def main():
             traffic = tj.get(dom)
             requests = tj.get("_read_requests", {}).get(dom)
             valu = tj.get("_valu_instructions", {})
+        # bytes of the layout the per-frame kernels actually read and write: position planes 36 B/triangle, one 64-byte
+        # triangle record and one 4-byte entry (written once, read once) per binned (sub-triangle, bin) pair, RGBA8 +
+        # depth + ramp index written and ramp index read + ASCII written per cell
+        layout_bytes = args.tris * 36 + entries * (64 + 8) + args.cols * args.rows * (9 + 2)
+        measured_frame = sum(v for k, v in tj.items() if not k.startswith("_") and isinstance(v, (int, float)) and k in kern_serial)
         line = {
             "metric": "frames/sec at 1920x1080 cell grid, 1M tris", "value": fps, "unit": "frames/s",
             "mtri_per_s": fps * args.tris / 1e6,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "rounds": rounds,
+            "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32+f64",
             "data": "synthetic",
-            "config": {"workload": "random mesh mulberry32(0xA5C11), %d tris, %dx%d cells, camera at origin, default lights, "
-                                   "modal smoothing on" % (args.tris, args.cols, args.rows),
+            "config": {"workload": "random mesh mulberry32(0xA5C11), %d tris, %dx%d cells, camera at origin with a per-frame yaw "
+                                   "jitter of +-%.2f rad, default lights, modal smoothing on" % (args.tris, args.cols, args.rows, YAW_JITTER),
                        "partition": "1 GPU" if not gather else "%d row strips, RCCL all-gather of the ASCII strips every %d frames" % (world, max(1, args.gather_batch)),
                        "algorithmic_bytes_per_frame": ar.scenes.algorithmic_bytes(args.tris, args.cols, args.rows),
-                       "frame_hbm_frac": ar.scenes.algorithmic_bytes(args.tris, args.cols, args.rows) * fps / 1e9 / HBM_PEAK_GBPS,
+                       "reference_layout_hbm_frac": ar.scenes.algorithmic_bytes(args.tris, args.cols, args.rows) * fps / 1e9 / HBM_PEAK_GBPS,
+                       "layout_bytes_per_frame": layout_bytes,
+                       "layout_hbm_frac": layout_bytes * fps / 1e9 / HBM_PEAK_GBPS,
+                       "measured_traffic_bytes_per_frame": measured_frame or None,
+                       "traffic_over_layout": (measured_frame / layout_bytes) if (measured_frame and not gather) else None,
                        "queued_records": counters},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
@@ -224,6 +385,7 @@ def main():
             "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
             "kernels_avg_us_serial": {k: round(v, 2) for k, v in kern_serial.items()},
         }
+        line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ar, sc)
         print(json.dumps(line), file=result_out, flush=True)
@@ -231,7 +393,8 @@ def main():
     if gather:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -95,7 +95,9 @@ int ar_set_ascii(ar_ctx *ctx, const uint8_t *ramp, int ramp_len, int mode_on, in
 
 /* Restricts rendering to output rows [row0, row1) of the frame (screen-strip partition for multi-GPU
  * runs; no counterpart in the single-GPU reference).  row0 = 0, row1 = 0 means the whole frame.
- * Rows outside the strip are left untouched in every output buffer. */
+ * ASCII rows outside the strip are left untouched.  With smoothing on, the rgba / depth (and id) planes are
+ * also written for up to three rows on either side of the strip - the smoothing window's halo, rendered
+ * exactly as a full frame would render them; rows beyond that are left untouched. */
 int ar_set_strip(ar_ctx *ctx, int row0, int row1);
 
 /* Renders one frame at cols x rows cells and blocks until done.
@@ -145,7 +147,7 @@ int ar_set_stream(ar_ctx *ctx, void *hip_stream);
  * context's: frame row r is written at d_ascii + (r - first_row) * cols, only for the rows of the
  * current strip, so a strip can be written densely into a slot of a larger gather buffer.  While a
  * target is set, ar_read / ar_render return the ASCII plane of the last frame rendered without one.
- * NULL returns to the context's own buffer.  No counterpart in the reference. */
+ * d_ascii must be 4-byte aligned.  NULL returns to the context's own buffer.  No counterpart in the reference. */
 int ar_set_ascii_target(ar_ctx *ctx, void *d_ascii, int first_row);
 
 /* Stream-ordered hand-over of the outputs, without blocking the host (no counterpart in the reference;
@@ -236,7 +238,7 @@ int ar_frame_counters(ar_ctx *ctx, uint32_t out[8]);
  *   AR_OPT_PATH          0 (default): tile-binned path whenever the grid has at most 8000 tiles of
  *                        64x32 cells, else the direct path; 1: always the direct path (every
  *                        fragment resolved with a 64-bit atomic min in HBM).
- *   AR_OPT_OVERLAP       1 or 2 (default): consecutive ar_render_async frames of the tiled path run on three
+ *   AR_OPT_OVERLAP       1 (default): consecutive ar_render_async frames of the tiled path run on three
  *                        streams of the context in rotation, each with its own set of buffers, so that up to
  *                        three frames share the GPU (no events between them); 0: one stream, frames strictly
  *                        one after the other.  ar_render (blocking) never overlaps.

@@ -115,7 +115,7 @@ def main():
             bad += 0 if rt_check(R, rng, n) else 1
             continue
         c = make_case(rng)
-        R.set_option("path", c["path"]); R.set_option("pool_records", c["pool"]); R.set_option("overlap", c["overlap"])
+        R.set_option("path", c["path"]); R.set_option("pool_records", c["pool"]); R.set_option("overlap", min(c["overlap"], 1))
         if c["indexed"] is not None:
             R.set_mesh_indexed(*c["indexed"])
         else:

@@ -30,6 +30,6 @@ for name, sc in cases:
     resident = n / (time.perf_counter() - t0)
     R.set_profiling(True); R.kernel_stats(); R.set_option("overlap", 0)
     for _ in range(100): R.render_async(cols, rows)
-    st = R.kernel_stats(); R.set_profiling(False); R.set_option("overlap", 2)
+    st = R.kernel_stats(); R.set_profiling(False); R.set_option("overlap", 1)
     us = {k: round(1e3 * ms / c, 1) for k, (c, ms) in st.items() if c}
     print("%-34s blocking+readback %7.0f frames/s (%.1f us)   resident %7.0f frames/s   kernels us %s" % (name, blocking, 1e6 / blocking, resident, us), flush=True)

@@ -25,7 +25,7 @@ for world in (1, 2, 4, 8):
             best = max(best, n / (time.perf_counter() - t0))
         R.set_profiling(True); R.kernel_stats(); R.set_option("overlap", 0)
         for _ in range(50): R.render_async(cols, rows)
-        st = R.kernel_stats(); R.set_profiling(False); R.set_option("overlap", 2)
+        st = R.kernel_stats(); R.set_profiling(False); R.set_option("overlap", 1)
         us = {k: round(1e3 * ms / n, 1) for k, (n, ms) in st.items() if n}
         print("world %d rank %d rows [%d,%d): %8.0f frames/s   serial kernel us %s" % (world, rank, r0, r1, best, us), flush=True)
         worst = best if worst is None else min(worst, best)

@@ -107,6 +107,68 @@ def test_c5_shape_point_lights_dense(pkg, oracle, R):
     _check(pkg, oracle, R, sc)
 
 
+def test_c4_4k_with_smoothing(pkg, oracle, R):
+    """C4 with the modal filter on: the smoothing kernel and its halo at 3840 x 2160."""
+    sc = pkg.scenes.random_scene(1_000_000, 3840, 2160)
+    _check(pkg, oracle, R, sc, mode=(True, 2, 12))
+
+
+def test_c5_full_size_ten_million_triangles(pkg, oracle, R):
+    """C5 as BASELINE states it: 10M triangles, 4 point lights, 1920 x 1080."""
+    sc = pkg.scenes.random_scene(10_000_000, 1920, 1080, seed=0xA5C12, point_lights=True)
+    out, ids = _check(pkg, oracle, R, sc)
+    assert np.unique(ids).size > 500_000
+
+
+@pytest.mark.parametrize("config", ["C4", "C5"])
+def test_multi_gpu_configs_cut_into_strips(pkg, oracle, config):
+    """The screen-strip partition of the two configurations meant for several GPUs, on the HIP path: the frame cut
+    into 2 / 4 / 8 row strips with ar_set_strip, every strip rendered on its own (smoothing on, so with its halo),
+    the bands put together again and compared with the oracle's full frame."""
+    if config == "C4":
+        sc = pkg.scenes.random_scene(1_000_000, 3840, 2160)
+    else:
+        sc = pkg.scenes.random_scene(10_000_000, 1920, 1080, seed=0xA5C12, point_lights=True)
+    cols, rows = sc["cols"], sc["rows"]
+    rgba, depth, _ids = oracle.render(sc["vbo"], sc["idx"], sc["proj"], sc["view"], sc["lights"], cols, rows, want_ids=False)
+    asc = oracle.quantize(rgba, cols, rows, pkg.scenes.DEFAULT_RAMP, 1, 2, 12)
+    r = pkg.Renderer(0)
+    try:
+        pkg.scenes.upload(r, sc)
+        for n in (2, 4, 8):
+            h = rows // n
+            got_a = np.zeros_like(asc); got_c = np.zeros_like(rgba); got_d = np.zeros_like(depth)
+            for k in range(n):
+                r.set_strip(k * h, (k + 1) * h)
+                o = r.render(cols, rows)
+                s = slice(k * h, (k + 1) * h)
+                got_a[s], got_c[s], got_d[s] = o["ascii"][s], o["rgba"][s], o["depth"][s]
+            assert np.array_equal(got_a, asc), "%s in %d strips: ASCII" % (config, n)
+            assert np.array_equal(got_c, rgba), "%s in %d strips: RGBA" % (config, n)
+            assert np.array_equal(got_d.view(np.uint32), depth.view(np.uint32)), "%s in %d strips: depth" % (config, n)
+        r.set_strip(0, 0)
+    finally:
+        r.close()
+
+
+def test_thousands_of_triangles_in_one_tile(pkg, oracle, R):
+    """24000 triangles of all sizes heaped on a patch of about 30 x 30 cells: the tile's work list fills and is
+    rasterised several times over, and the list of swept triangles overflows into the per-lane scan."""
+    rng = np.random.default_rng(5)
+    T = 24000
+    centre = np.array([5.0, 0.3, 0.2]) + rng.uniform(-0.5, 0.5, size=(T, 1, 3)) * np.array([0.3, 1.0, 1.0])
+    P = (centre + rng.uniform(-1, 1, size=(T, 3, 3)) * rng.choice([0.02, 0.1, 0.6], p=[0.5, 0.3, 0.2], size=(T, 1, 1))).reshape(-1, 3)
+    vbo, idx = pkg.host.mesh_to_vbo(P.astype(np.float32), np.arange(T * 3).reshape(-1, 3), rng.uniform(0, 1, size=(T, 3)))
+    for cols, rows in ((320, 200), (127, 33)):
+        proj, view = pkg.host.camera_matrices({"pos": (0.0, 0.0, 0.0), "yaw": 0.0, "pitch": 0.0}, cols, rows, 1.0)
+        sc = {"name": "heap %dx%d" % (cols, rows), "vbo": vbo, "idx": idx, "proj": proj, "view": view, "lights": pkg.host.pack_lights({}),
+              "cols": cols, "rows": rows}
+        for _ in range(3):
+            _check(pkg, oracle, R, sc)
+        if R.path_name == "tiled" and cols == 320:
+            assert R.frame_counters()["bin_records"] > 3 * 2048      # (one bin holds nearly all of them)
+
+
 def test_near_plane_and_huge_triangles(pkg, oracle, R):
     """Random large triangles all around (and through) the camera: clipping, culling, all three passes."""
     rng = np.random.default_rng(7)
