@@ -14,10 +14,11 @@ strips are combined by RCCL all-gathers (total work fixed: "strong" scaling).
 parent - before it has touched the GPU in any way - runs `python -m torch.distributed.run` as a child
 process, relays rank 0's JSON line and exits with the child's status.
 
-Timing: W untimed warm-up frames, then rounds of exactly K frames, each round bracketed by a barrier and
-a full synchronisation and taken as the MAX over ranks; rounds are repeated until at least 0.25 s has been
-measured and the median round is reported (`rounds` in the line), so that a short K does not make the
-result a one-millisecond sample.  Rank 0 prints ONE JSON line.
+Timing: W untimed warm-up frames, then rounds of K frames (when K frames take under 10 ms, a whole number of
+K-frame blocks back to back, `frames_per_round` in the line), each round bracketed by a barrier and a full
+synchronisation and taken as the MAX over ranks; rounds are repeated until at least 0.25 s has been measured
+and the median round is reported (`rounds`), so that a short K makes the result neither a one-millisecond
+sample nor a measurement of pipeline fill and drain.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import importlib
@@ -39,6 +40,7 @@ PEAK_CLOCK_HZ = 2.4e9        # peak engine clock
 N_TRIS = 1_000_000
 COLS, ROWS = 1920, 1080
 MIN_TIMED_S = 0.25           # rounds of --steps frames are repeated until this much has been measured
+MIN_ROUND_S = 0.01           # a round is at least this long: --steps frames, or a whole number of such blocks back to back
 MAX_ROUNDS = 400
 YAW_JITTER = 0.01            # radians either side of the workload's view direction
 N_CAMERAS = 64
@@ -237,18 +239,24 @@ def main(argv=None):
         return dt
 
     def measure(n, b=None):
-        """Rounds of n frames until MIN_TIMED_S has been measured (the count follows from the first round's
-        all-rank maximum, so every rank runs the same number); (median round seconds, rounds)."""
+        """Rounds until MIN_TIMED_S has been measured; (median seconds per frame, rounds, frames per round).
+        A round of n frames that lasts under MIN_ROUND_S is mostly pipeline fill and drain (a frame's latency is
+        about two frame times), so short rounds are run as a whole number of n-frame blocks back to back; the
+        counts follow from the first block's all-rank maximum, so every rank runs the same."""
         first = timed_round(n, b)
-        rounds = min(MAX_ROUNDS, max(1, int(math.ceil(MIN_TIMED_S / max(first, 1e-9)))))
-        dts = sorted([first] + [timed_round(n, b) for _ in range(rounds - 1)])
-        return dts[len(dts) // 2] if len(dts) % 2 else 0.5 * (dts[len(dts) // 2 - 1] + dts[len(dts) // 2]), len(dts)
+        blocks = max(1, int(math.ceil(MIN_ROUND_S / max(first, 1e-9))))
+        per_round = n * blocks
+        one = first if blocks == 1 else timed_round(per_round, b)
+        rounds = min(MAX_ROUNDS, max(1, int(math.ceil(MIN_TIMED_S / max(one, 1e-9)))))
+        dts = sorted([one] + [timed_round(per_round, b) for _ in range(rounds - 1)])
+        med = dts[len(dts) // 2] if len(dts) % 2 else 0.5 * (dts[len(dts) // 2 - 1] + dts[len(dts) // 2])
+        return med / per_round, len(dts), per_round
 
     for _ in range(args.warmup):
         step(batcher)
     fence(batcher)
-    dt, rounds = measure(args.steps, batcher)
-    fps = args.steps / dt
+    frame_s, rounds, frames_per_round = measure(args.steps, batcher)
+    fps = 1.0 / frame_s
 
     extras = {}
     gather_ok = None
@@ -269,8 +277,7 @@ def main(argv=None):
             for _ in range(args.warmup):
                 step(b1)
             fence(b1)
-            dt1, _r = measure(args.steps, b1)
-            extras["fps_gather_every_frame"] = args.steps / dt1
+            extras["fps_gather_every_frame"] = 1.0 / measure(args.steps, b1)[0]
         R.set_ascii_target(None)
 
     # per-kernel durations (HIP events on the renderer's streams) over a pass of plain frames
@@ -355,7 +362,7 @@ def main(argv=None):
             "metric": "frames/sec at 1920x1080 cell grid, 1M tris", "value": fps, "unit": "frames/s",
             "mtri_per_s": fps * args.tris / 1e6,
             "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "rounds": rounds,
-            "ms_per_step": 1e3 * dt / args.steps,
+            "frames_per_round": frames_per_round, "ms_per_step": 1e3 * frame_s,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32+f64",
             "data": "synthetic",
             "config": {"workload": "random mesh mulberry32(0xA5C11), %d tris, %dx%d cells, camera at origin with a per-frame yaw "
