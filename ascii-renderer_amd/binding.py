@@ -17,7 +17,7 @@ EXPORTS = [
     "ar_device_buffer", "ar_stream", "ar_host_alloc", "ar_host_free", "ar_stream_wait_frame", "ar_frame_wait_stream", "ar_set_stream",
     "ar_set_ascii_target", "ar_quantize", "ar_quantize_colors", "ar_read_colors", "ar_present", "ar_set_profiling", "ar_kernel_stats",
     "ar_frame_counters", "ar_set_option", "ar_set_mesh_uv", "ar_set_texture", "ar_set_mesh_indexed", "ar_read_mesh",
-    "ar_rt_set_scene", "ar_rt_render", "ar_rt_render_async",
+    "ar_rt_set_scene", "ar_rt_render", "ar_rt_render_async", "ar_quantize_static",
 ]
 _lib = None
 
@@ -97,6 +97,8 @@ def load_library():
     L.ar_stream_wait_frame.argtypes = [vp, vp]
     L.ar_frame_wait_stream.argtypes = [vp, vp]
     L.ar_quantize.argtypes = [vp, _u8p, ctypes.c_int, ctypes.c_int, _u8p]
+    L.ar_quantize_static.argtypes = [vp, _u8p, ctypes.c_int, ctypes.c_int, _u8p]
+    L.ar_quantize_static.restype = ctypes.c_int
     L.ar_quantize_colors.argtypes = [vp, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _u32p]
     L.ar_read_colors.argtypes = [vp, ctypes.c_int, ctypes.c_int, _u32p]
     L.ar_present.argtypes = [vp, _u8p, ctypes.c_int, ctypes.c_int, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_double,
@@ -349,6 +351,15 @@ class Renderer:
             raise ValueError("rgba size does not match cols*rows*4")
         out = np.zeros((rows, cols), dtype=np.uint8)
         self._check(self._L.ar_quantize(self._h, rgba.ctypes.data_as(_u8p), int(cols), int(rows), out.ctypes.data_as(_u8p)))
+        return out
+
+    def quantize_static(self, rgba, cols, rows):
+        """quantize() through the library's fixed staging array: no device allocation on the way."""
+        rgba = np.ascontiguousarray(np.asarray(rgba, dtype=np.uint8).reshape(-1))
+        if rgba.size != cols * rows * 4:
+            raise ValueError("rgba size does not match cols*rows*4")
+        out = np.zeros((rows, cols), dtype=np.uint8)
+        self._check(self._L.ar_quantize_static(self._h, rgba.ctypes.data_as(_u8p), int(cols), int(rows), out.ctypes.data_as(_u8p)))
         return out
 
     def quantize_colors(self, rgba, cols, rows, steps=0, grayscale=False):

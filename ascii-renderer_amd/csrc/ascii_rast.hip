@@ -25,6 +25,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -38,6 +39,38 @@
 #include "ascii_stage.h"
 #include "raytrace.h"
 #include "context.h"
+
+// ---- ar_quantize without allocations ------------------------------------------------------------------------
+// ar_quantize stages the caller's RGBA grid and the ASCII plane in device memory that it allocates (and grows) on
+// demand.  The variant below stages them in a fixed array that is part of the loaded code object instead, so that
+// it never calls hipMalloc / hipFree: for callers that cannot allocate (under HIP graph capture, in serving loops
+// and harnesses that forbid it).  Every GPU the library runs on holds its own copy of the array until the process
+// ends; all calls on a GPU share it, so calls that overlap on one GPU race, and it keeps the last call's contents
+// (nothing in it has to start at zero: a call overwrites every byte it later reads).
+static __device__ __align__(256) unsigned char scratch[size_t(AR_STATIC_MAX_CELLS) * 5];  // RGBA staging, then the ASCII plane
+
+namespace {
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[kMaxDevices] = {};  // device address of `scratch` on each GPU (the symbol's name is only a host-side handle)
+
+// Address of this device's copy of the array; looked up once per device, with that device current.
+int static_scratch(ar_ctx *ctx, unsigned char **out) {
+    if (ctx->device < 0 || ctx->device >= kMaxDevices) return fail(ctx, AR_E_ARG, "device %d beyond the %d the static staging array is tracked for", ctx->device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[ctx->device]) {
+        AR_HIP(ctx, hipSetDevice(ctx->device));
+        void *p = nullptr;
+        AR_HIP(ctx, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(ctx, AR_E_HIP, "hipGetSymbolAddress returned a null address for the static staging array");
+        g_scratch_ptr[ctx->device] = static_cast<unsigned char *>(p);
+    }
+    *out = g_scratch_ptr[ctx->device];
+    return 0;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -64,6 +97,14 @@ ar_ctx *ar_create(int device_id) {
         fail(nullptr, AR_E_HIP, "context setup failed: %s", hipGetErrorString(hipGetLastError()));
         ar_destroy(ctx);
         return nullptr;
+    }
+    {   // this device's copy of the static staging array (ar_quantize_static): its address is looked up here, once per device
+        unsigned char *p = nullptr;
+        if (static_scratch(ctx, &p) != 0) {
+            fail(nullptr, AR_E_HIP, "context setup failed: %s", ctx->err);
+            ar_destroy(ctx);
+            return nullptr;
+        }
     }
     memset(&ctx->fp, 0, sizeof ctx->fp);
     static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -385,6 +426,32 @@ int ar_quantize(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *a
     if (rc) return rc;
     AR_HIP(ctx, hipMemcpyAsync(ascii, ctx->d_q_ascii, size_t(cols) * rows, hipMemcpyDeviceToHost, ctx->stream));
     AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ar_quantize through the static staging array (defined above ar_create): no hipMalloc / hipFree on this path.
+int ar_quantize_static(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *ascii) {
+    if (!ctx) return AR_E_ARG;
+    if (!rgba || !ascii || cols <= 0 || rows <= 0) return fail(ctx, AR_E_ARG, "ar_quantize_static: bad arguments (%d x %d)", cols, rows);
+    const size_t n = size_t(cols) * size_t(rows);
+    if (n > size_t(AR_STATIC_MAX_CELLS))
+        return fail(ctx, AR_E_ARG, "ar_quantize_static: %d x %d = %zu cells exceed the static staging array's %d cells (use ar_quantize)",
+                    cols, rows, n, AR_STATIC_MAX_CELLS);
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned char *base = nullptr;
+    int rc = static_scratch(ctx, &base);  // (looked up at ar_create; this is the fallback for a context whose creation could not)
+    if (rc) return rc;
+    uint8_t *d_rgba = base, *d_ascii = base + size_t(AR_STATIC_MAX_CELLS) * 4;
+    FrameParams fp = ctx->fp;
+    fp.cols = cols; fp.rows = rows; fp.row0 = 0; fp.row1 = rows; fp.ya = 0; fp.yb = rows;
+    AR_HIP(ctx, hipMemcpyAsync(d_rgba, rgba, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (fp.mode_on == 1) launch_ascii<true>(fp, d_rgba, d_ascii, ctx->stream);
+    else k_quantize_plain<<<unsigned((n + 255) / 256), 256, 0, ctx->stream>>>(fp, reinterpret_cast<const uint32_t *>(d_rgba), d_ascii, n);
+    hipError_t launched = hipGetLastError();
+    if (launched == hipSuccess) launched = hipMemcpyAsync(ascii, d_ascii, n, hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t done = hipStreamSynchronize(ctx->stream);  // also on failure: the copy of the caller's buffer must not outlive the call
+    if (launched != hipSuccess) return fail(ctx, AR_E_HIP, "ar_quantize_static: %s", hipGetErrorString(launched));
+    if (done != hipSuccess) return fail(ctx, AR_E_HIP, "ar_quantize_static: %s", hipGetErrorString(done));
     return 0;
 }
 

@@ -165,6 +165,15 @@ int ar_frame_wait_stream(ar_ctx *ctx, void *hip_stream);
  * twins compositeAndQuantize (js/renderer.js:59-72) / _computeRowString (js/text_overlay.js:128-148). */
 int ar_quantize(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *ascii);
 
+/* ar_quantize for callers that cannot allocate: same arguments, same result, but the grid and the ASCII plane are
+ * staged in a fixed device array that is part of the library's code object (AR_STATIC_MAX_CELLS x 5 bytes on every
+ * GPU the library runs on, held until the process ends), so the call makes no hipMalloc / hipFree.  It has NO
+ * counterpart in the reference; it exists for callers under HIP graph capture, tight serving loops and harnesses that
+ * forbid allocation.  Grids of more than AR_STATIC_MAX_CELLS cells are rejected with AR_E_ARG.  All calls on one GPU
+ * share the array (whatever context they are made on): calls that overlap on one GPU race. */
+#define AR_STATIC_MAX_CELLS (1920 * 1080)
+int ar_quantize_static(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *ascii);
+
 /* RGBA8 grid -> RGBA8 image of coloured glyphs, cols*cell_w x rows*cell_h pixels, row 0 = top.
  * Replaces: AsciiPass.drawFromBuffer in full - the index half as ar_quantize, then the compositing half of
  * the fragment shader (js/ascii_pass_shader.js:190-230): per pixel the nearest texel of the cell's glyph,
