@@ -17,7 +17,7 @@ EXPORTS = [
     "ar_device_buffer", "ar_stream", "ar_host_alloc", "ar_host_free", "ar_stream_wait_frame", "ar_frame_wait_stream", "ar_set_stream",
     "ar_set_ascii_target", "ar_quantize", "ar_quantize_colors", "ar_read_colors", "ar_present", "ar_set_profiling", "ar_kernel_stats",
     "ar_frame_counters", "ar_set_option", "ar_set_mesh_uv", "ar_set_texture", "ar_set_mesh_indexed", "ar_read_mesh",
-    "ar_rt_set_scene", "ar_rt_render", "ar_rt_render_async", "ar_quantize_static",
+    "ar_rt_set_scene", "ar_rt_render", "ar_rt_render_async", "ar_quantize_static", "ar_set_model",
 ]
 _lib = None
 
@@ -76,6 +76,8 @@ def load_library():
     L.ar_set_mesh_uv.argtypes = [vp, ctypes.POINTER(ctypes.c_uint16), ctypes.c_uint32]
     L.ar_set_texture.argtypes = [vp, _u8p, ctypes.c_int, ctypes.c_int]
     L.ar_set_camera.argtypes = [vp, _fp, _fp]
+    L.ar_set_model.argtypes = [vp, _fp]
+    L.ar_set_model.restype = ctypes.c_int
     L.ar_set_lights.argtypes = [vp, _fp, _fp, _fp, ctypes.c_int, _fp, _fp]
     L.ar_set_ascii.argtypes = [vp, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.ar_set_strip.argtypes = [vp, ctypes.c_int, ctypes.c_int]
@@ -239,6 +241,16 @@ class Renderer:
         if _p.size != 16 or _v.size != 16:
             raise ValueError("proj and view must have 16 elements")
         self._check(self._L.ar_set_camera(self._h, pp, vp))
+
+    def set_model(self, model):
+        """Column-major 4x4 model matrix applied to the current mesh on the GPU; None removes it."""
+        if model is None:
+            self._check(self._L.ar_set_model(self._h, None))
+            return
+        _m, mp = _f32(np.asarray(model).reshape(-1))
+        if _m.size != 16:
+            raise ValueError("model must have 16 elements")
+        self._check(self._L.ar_set_model(self._h, mp))
 
     @staticmethod
     def prepare_camera(proj, view):

@@ -248,6 +248,13 @@ int ar_set_camera(ar_ctx *ctx, const float proj[16], const float view[16]) {
     return 0;
 }
 
+int ar_set_model(ar_ctx *ctx, const float model[16]) {
+    if (!ctx) return AR_E_ARG;
+    ctx->has_model = model != nullptr;
+    if (model) memcpy(ctx->model, model, 16 * sizeof(float));
+    return 0;
+}
+
 int ar_set_lights(ar_ctx *ctx, const float amb[3], const float dir[3], const float dircol[3], int n_pl,
                   const float *plpos, const float *plcol) {
     if (!ctx) return AR_E_ARG;

@@ -25,6 +25,8 @@ struct ar_ctx {
     uint32_t *d_idx = nullptr;
     uint32_t n_verts = 0, n_tris = 0;
     float proj[16], view[16];
+    float model[16];           // column-major model matrix (ar_set_model)
+    bool has_model = false;
     FrameParams fp;
     int strip0 = 0, strip1 = 0;
     int cols = 0, rows = 0;  // size of the current targets
@@ -232,6 +234,14 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
     fp.ya = row0 - halo < 0 ? 0 : row0 - halo;
     fp.yb = row1 + halo > rows ? rows : row1 + halo;
     matmul_pv(ctx->proj, ctx->view, fp.pv);
+    fp.has_model = ctx->has_model ? 1 : 0;
+    if (ctx->has_model) {  // uProj * uView * uModel * v: GLSL multiplies the matrices first, left to right
+        float pv[16];
+        memcpy(pv, fp.pv, sizeof pv);
+        matmul_pv(pv, ctx->model, fp.pv);
+        for (int c = 0; c < 4; c++)
+            for (int r = 0; r < 3; r++) fp.model[3 * c + r] = ctx->model[4 * c + r];
+    }
     // texturing needs texel coordinates, an atlas, and more than one texel either way (shader_utils.js:94)
     const bool textured = ctx->d_triuv && ctx->d_atlas && ctx->atlas_w > 1 && ctx->atlas_h > 1;
     fp.tex_w = textured ? ctx->atlas_w : 0;

@@ -210,6 +210,20 @@ napi_value js_set_camera(napi_env env, napi_callback_info info) {
     return nullptr;
 }
 
+// setModel(handle, Float32Array(16) | null): ar_set_model
+napi_value js_set_model(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    void *m;
+    size_t n;
+    if (!get_typed(env, argv[1], napi_float32_array, &m, &n, true)) return nullptr;
+    if (m && n != 16) { napi_throw_range_error(env, nullptr, "setModel: Float32Array(16) or null expected"); return nullptr; }
+    if (ar_set_model(ctx, static_cast<const float *>(m))) return throw_ar(env, ctx, "ar_set_model");
+    return nullptr;
+}
+
 napi_value js_set_lights(napi_env env, napi_callback_info info) {
     napi_value argv[6];
     if (!get_args(env, info, 6, argv)) return nullptr;
@@ -487,6 +501,7 @@ napi_value init(napi_env env, napi_value exports) {
         {"setMeshUv", nullptr, js_set_mesh_uv, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setTexture", nullptr, js_set_texture, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setCamera", nullptr, js_set_camera, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setModel", nullptr, js_set_model, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setLights", nullptr, js_set_lights, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setAscii", nullptr, js_set_ascii, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"setStrip", nullptr, js_set_strip, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

@@ -18,7 +18,9 @@ const char *const kKernelNames[AR_N_KERNELS] = {"k_clear",  "k_raster", "k_raste
 
 // Everything a frame's kernels need besides the big buffers; passed by value as a kernel argument.
 struct FrameParams {
-    float pv[16];  // P*V, column-major
+    float pv[16];  // P*V (times the model matrix when one is set), column-major
+    float model[12];  // model matrix without its bottom row: model[3 * c + r] = M[c][r], r < 3 (ar_set_model)
+    int has_model;    // 0: no model matrix (world position and normal are the vertex's own)
     float amb[3], ldir[3], lcol[3];
     float plpos[3 * AR_MAX_POINT_LIGHTS], plcol[3 * AR_MAX_POINT_LIGHTS];
     int n_pl;
@@ -60,6 +62,19 @@ __device__ __forceinline__ KernargFrameParams *kernarg_params() {
     return q;
 }
 
+// World position M * (x, y, z, 1) and world normal mat3(M) * n of a vertex under the model matrix: what a vertex
+// shader with a uModel uniform hands on as v_pos and v_nrm.
+template <typename FP>
+__device__ __forceinline__ void model_point(const FP &fp, float x, float y, float z, float *o) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) o[r] = ((fp.model[r] * x + fp.model[3 + r] * y) + fp.model[6 + r] * z) + fp.model[9 + r];
+}
+template <typename FP>
+__device__ __forceinline__ void model_normal(const FP &fp, float x, float y, float z, float *o) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) o[r] = (fp.model[r] * x + fp.model[3 + r] * y) + fp.model[6 + r] * z;
+}
+
 template <int NV>
 struct Vert {
     float c[4];                // clip x, y, z, w
@@ -79,6 +94,10 @@ __device__ __forceinline__ Vert<NV> load_vertex(const FrameParams &fp, const flo
         o.v[0] = x; o.v[1] = y; o.v[2] = z;
 #pragma unroll
         for (int k = 3; k < NV; k++) o.v[k] = k < 9 ? p[k] : 0.0f;  // beyond the buffer's nine: texel coordinates, set by the caller
+        if (fp.has_model) {
+            model_point(fp, x, y, z, o.v);
+            model_normal(fp, p[3], p[4], p[5], o.v + 3);
+        }
     }
     return o;
 }

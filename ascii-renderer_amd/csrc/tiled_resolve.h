@@ -63,7 +63,21 @@ __device__ __forceinline__ void shade_clipped_record(const FrameParams &fp, cons
         return (b0 * sv[0] + b1 * sv[1]) + b2 * sv[2];
     };
     float v[9];
-    for (int q = 0; q < 9; q++) v[q] = varying(vp[0][q], vp[1][q], vp[2][q]);
+    if (fp.has_model) {
+        // world position and normal of the three mesh vertices under the model matrix, one component at a time
+        for (int q = 0; q < 6; q++) {
+            const int r = q < 3 ? q : q - 3, o = q < 3 ? 0 : 3;
+            float w[3];
+            for (int k = 0; k < 3; k++) {
+                w[k] = (fp.model[r] * vp[k][o] + fp.model[3 + r] * vp[k][o + 1]) + fp.model[6 + r] * vp[k][o + 2];
+                if (q < 3) w[k] = w[k] + fp.model[9 + r];
+            }
+            v[q] = varying(w[0], w[1], w[2]);
+        }
+        for (int q = 6; q < 9; q++) v[q] = varying(vp[0][q], vp[1][q], vp[2][q]);
+    } else {
+        for (int q = 0; q < 9; q++) v[q] = varying(vp[0][q], vp[1][q], vp[2][q]);
+    }
     if (TEX && (flags & kFlagTextured)) {
         const uint4 uv = triuv[t];
         const float tu = varying(float(uv.x & 0xFFFFu), float(uv.y & 0xFFFFu), float(uv.z & 0xFFFFu));
@@ -107,9 +121,11 @@ __device__ __forceinline__ void shade_from_triangle(const FrameParams &fp, const
     float v[9];
     if (ts.flags & kFlagFlat) {
         // the same three-term sum as for a smooth triangle, with one value at all three vertices
+        float n[3] = {ts.n[0], ts.n[1], ts.n[2]};
+        if (kp.has_model) model_normal(kp, ts.n[0], ts.n[1], ts.n[2], n);
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-            v[3 + q] = (b0 * ts.n[q] + b1 * ts.n[q]) + b2 * ts.n[q];
+            v[3 + q] = (b0 * n[q] + b1 * n[q]) + b2 * n[q];
             v[6 + q] = (b0 * ts.c[q] + b1 * ts.c[q]) + b2 * ts.c[q];
         }
     } else {
@@ -117,16 +133,30 @@ __device__ __forceinline__ void shade_from_triangle(const FrameParams &fp, const
         const float4 a0 = row[0], a1 = row[2], a2 = row[4];
         const float2 c0 = *reinterpret_cast<const float2 *>(row + 1), c1 = *reinterpret_cast<const float2 *>(row + 3),
                      c2 = *reinterpret_cast<const float2 *>(row + 5);
-        v[3] = (b0 * a0.x + b1 * a1.x) + b2 * a2.x;
-        v[4] = (b0 * a0.y + b1 * a1.y) + b2 * a2.y;
-        v[5] = (b0 * a0.z + b1 * a1.z) + b2 * a2.z;
+        float n0[3] = {a0.x, a0.y, a0.z}, n1[3] = {a1.x, a1.y, a1.z}, n2[3] = {a2.x, a2.y, a2.z};
+        if (kp.has_model) {
+            model_normal(kp, a0.x, a0.y, a0.z, n0);
+            model_normal(kp, a1.x, a1.y, a1.z, n1);
+            model_normal(kp, a2.x, a2.y, a2.z, n2);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) v[3 + q] = (b0 * n0[q] + b1 * n1[q]) + b2 * n2[q];
         v[6] = (b0 * a0.w + b1 * a1.w) + b2 * a2.w;
         v[7] = (b0 * c0.x + b1 * c1.x) + b2 * c2.x;
         v[8] = (b0 * c0.y + b1 * c1.y) + b2 * c2.y;
     }
     if (kp.n_pl > 0) {
+        if (kp.has_model) {
+            float w0[3], w1[3], w2[3];
+            model_point(kp, ts.p[0], ts.p[1], ts.p[2], w0);
+            model_point(kp, ts.p[3], ts.p[4], ts.p[5], w1);
+            model_point(kp, ts.p[6], ts.p[7], ts.p[8], w2);
 #pragma unroll
-        for (int q = 0; q < 3; q++) v[q] = (b0 * ts.p[q] + b1 * ts.p[3 + q]) + b2 * ts.p[6 + q];
+            for (int q = 0; q < 3; q++) v[q] = (b0 * w0[q] + b1 * w1[q]) + b2 * w2[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 3; q++) v[q] = (b0 * ts.p[q] + b1 * ts.p[3 + q]) + b2 * ts.p[6 + q];
+        }
     } else {
         v[0] = v[1] = v[2] = 0.0f;  // only the point-light loop reads the position
     }

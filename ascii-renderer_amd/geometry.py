@@ -72,6 +72,22 @@ def icosphere(subdiv=4, radius=1.0):
     return P, np.asarray(faces, dtype=np.uint32)
 
 
+def spin_matrix(angle, axis=(0.0, 1.0, 0.0), translate=(0.0, 0.0, 0.0), scale=1.0):
+    """Column-major model matrix (float32[16]): uniform scale, then rotation by `angle` about `axis`
+    (Rodrigues' formula in binary64), then translation - what a spinning mesh hands to ar_set_model per frame."""
+    ax = np.asarray(axis, dtype=np.float64)
+    ax = ax / math.sqrt(float(ax @ ax))
+    x, y, z = ax
+    c, s = math.cos(angle), math.sin(angle)
+    R = np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * s, x * z * (1 - c) + y * s],
+                  [y * x * (1 - c) + z * s, c + y * y * (1 - c), y * z * (1 - c) - x * s],
+                  [z * x * (1 - c) - y * s, z * y * (1 - c) + x * s, c + z * z * (1 - c)]]) * float(scale)
+    M = np.eye(4)
+    M[:3, :3] = R
+    M[:3, 3] = translate
+    return M.T.reshape(-1).astype(np.float32)
+
+
 def random_mesh(seed, n_tris, cols, rows, pixel_aspect=1.0, depth_range=(2.0, 60.0), cells=2.0,
                 chunk=1 << 20):
     """Screen-uniform cloud of small random triangles in front of a camera at the origin looking

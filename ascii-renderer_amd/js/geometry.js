@@ -16,6 +16,20 @@ export function mulberry32(a) {
   };
 }
 
+// Column-major model matrix (Float32Array(16)): uniform scale, then rotation by `angle` about `axis`, then
+// translation - what a spinning mesh hands to HipRasterBackend.setModelMatrix per frame (same arithmetic as
+// geometry.py: spin_matrix).
+export function spinMatrix(angle, axis, translate, scale) {
+  const a = axis || [0, 1, 0], t = translate || [0, 0, 0], k = scale === undefined ? 1.0 : +scale;
+  const L = Math.sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+  const x = a[0] / L, y = a[1] / L, z = a[2] / L, c = Math.cos(angle), s = Math.sin(angle);
+  return new Float32Array([
+    (c + x * x * (1 - c)) * k, (y * x * (1 - c) + z * s) * k, (z * x * (1 - c) - y * s) * k, 0,
+    (x * y * (1 - c) - z * s) * k, (c + y * y * (1 - c)) * k, (z * y * (1 - c) + x * s) * k, 0,
+    (x * z * (1 - c) + y * s) * k, (y * z * (1 - c) - x * s) * k, (c + z * z * (1 - c)) * k, 0,
+    t[0], t[1], t[2], 1]);
+}
+
 export function cube(half) {
   const h = half === undefined ? 0.5 : +half;
   const positions = new Float32Array([-h, -h, -h, h, -h, -h, h, h, -h, -h, h, -h, -h, -h, h, h, -h, h, h, h, h, -h, h, h]);

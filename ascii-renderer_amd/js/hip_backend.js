@@ -338,6 +338,14 @@ export class HipRasterBackend {
     }
   }
 
+  // A model matrix for the mesh (column-major, 16 numbers; null removes it), applied on the GPU from the next frame
+  // on: rigid motion of the scene without another setScene.  The reference's rasterizer has none
+  // (raster_shader.js:12-13); see ar_set_model.
+  setModelMatrix(m) {
+    this._ensure();
+    native().setModel(this._h, m ? (m instanceof Float32Array ? m : new Float32Array(m)) : null);
+  }
+
   render(timeSec, framebuffer, appState) {
     this._ensure();
     const w = ((appState && appState.cols) | 0) || (config.VIRTUAL_GRID_WIDTH | 0) || 1;

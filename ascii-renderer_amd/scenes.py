@@ -72,6 +72,7 @@ def upload(renderer, sc, ramp=DEFAULT_RAMP, mode_on=True, mode_radius=2, mode_th
     renderer.set_mesh_uv(sc.get("uv8"))        # set_mesh dropped any earlier coordinates; the atlas stays until replaced
     renderer.set_texture(sc.get("atlas"))
     renderer.set_camera(sc["proj"], sc["view"])
+    renderer.set_model(sc.get("model"))
     renderer.set_lights(sc["lights"])
     renderer.set_ascii(ramp, mode_on, mode_radius, mode_thresh)
 

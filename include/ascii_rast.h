@@ -83,6 +83,17 @@ int ar_set_texture(ar_ctx *ctx, const uint8_t *rgba, int width, int height);
  * (raster.js:296-304). */
 int ar_set_camera(ar_ctx *ctx, const float proj[16], const float view[16]);
 
+/* A model matrix for the current mesh (column-major 4 x 4; NULL removes it), applied per frame on the GPU: the
+ * mesh is drawn as if the reference's vertex shader (js/render/backends/raster_shader.js:17-22) read
+ *     gl_Position = uProj * uView * uModel * vec4(a_pos, 1);  v_pos = (uModel * vec4(a_pos, 1)).xyz;
+ *     v_nrm = mat3(uModel) * a_nrm;
+ * with the matrix product (uProj * uView) * uModel formed first, as GLSL evaluates it.  The reference's rasterizer
+ * has no model matrix (raster_shader.js:12-13) - its scenes move only by being rebuilt and uploaded again
+ * (raster.js:130-133) - so this replaces a setScene per frame for rigid motion: a spinning mesh costs sixteen
+ * floats per frame instead of a new vertex buffer.  Normals go through the upper-left 3 x 3 unchanged, which is
+ * exact for rotations, translations and uniform scales (the fragment shader normalises). */
+int ar_set_model(ar_ctx *ctx, const float model[16]);
+
 /* Light uniforms as packed by raster.js:307-342: uAmbient, uLightDir, uLightColor, uPLCount and the
  * first n_pl entries of uPLPos / uPLCol (n_pl <= AR_MAX_POINT_LIGHTS, 3 floats each). */
 int ar_set_lights(ar_ctx *ctx, const float amb[3], const float dir[3], const float dircol[3],

@@ -98,13 +98,26 @@ void orc_matmul_pv(const float *P, const float *V, float *PV)
                              P[2 * 4 + r] * V[c * 4 + 2]) + P[3 * 4 + r] * V[c * 4 + 3];
 }
 
-/* raster_shader.js:17-22: gl_Position = uProj * uView * vec4(a_pos, 1.0); varyings copied. */
-static void vertex_shader(const float *PV, const float *vtx9, orc_vert *o)
+/* raster_shader.js:17-22: gl_Position = uProj * uView * vec4(a_pos, 1.0); varyings copied.
+ * With a model matrix M (orc_render_model; the reference has none, raster_shader.js:12-13) the shader reads
+ *   gl_Position = uProj * uView * uModel * vec4(a_pos, 1.0)   - GLSL multiplies left to right, matrices first, so PV
+ *                                                               here is (P*V)*M, formed by the caller in binary32;
+ *   v_pos = (uModel * vec4(a_pos, 1.0)).xyz;  v_nrm = mat3(uModel) * a_nrm;  v_col = a_col
+ * (normals go through the upper-left 3x3 as they are: exact for rigid motions and uniform scales, since the
+ * fragment shader normalises). */
+static void vertex_shader(const float *PV, const float *M, const float *vtx9, orc_vert *o)
 {
     const float x = vtx9[0], y = vtx9[1], z = vtx9[2];
     for (int r = 0; r < 4; r++)
         o->c[r] = ((PV[0 * 4 + r] * x + PV[1 * 4 + r] * y) + PV[2 * 4 + r] * z) + PV[3 * 4 + r];
     for (int k = 0; k < 9; k++) o->v[k] = vtx9[k];
+    if (M) {
+        const float nx = vtx9[3], ny = vtx9[4], nz = vtx9[5];
+        for (int r = 0; r < 3; r++) {
+            o->v[r] = ((M[0 * 4 + r] * x + M[1 * 4 + r] * y) + M[2 * 4 + r] * z) + M[3 * 4 + r];
+            o->v[3 + r] = (M[0 * 4 + r] * nx + M[1 * 4 + r] * ny) + M[2 * 4 + r] * nz;
+        }
+    }
     o->v[9] = o->v[10] = 0.0f;
 }
 
@@ -280,6 +293,12 @@ int orc_render_textured(const float *vbo9, uint32_t n_verts, const uint32_t *idx
                         int n_pl, const float *plpos, const float *plcol,
                         int cols, int rows, uint8_t *rgba_out, float *depth_out, uint32_t *ids_out,
                         const uint16_t *uv8, const uint8_t *atlas_rgba, int atlas_w, int atlas_h);
+int orc_render_model(const float *vbo9, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris,
+                     const float *proj, const float *view, const float *model,
+                     const float *amb, const float *ldir, const float *lcol,
+                     int n_pl, const float *plpos, const float *plcol,
+                     int cols, int rows, uint8_t *rgba_out, float *depth_out, uint32_t *ids_out,
+                     const uint16_t *uv8, const uint8_t *atlas_rgba, int atlas_w, int atlas_h);
 
 int orc_render(const float *vbo9, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris,
                const float *proj, const float *view,
@@ -306,6 +325,22 @@ int orc_render_textured(const float *vbo9, uint32_t n_verts, const uint32_t *idx
                         int cols, int rows, uint8_t *rgba_out, float *depth_out, uint32_t *ids_out,
                         const uint16_t *uv8, const uint8_t *atlas_rgba, int atlas_w, int atlas_h)
 {
+    return orc_render_model(vbo9, n_verts, idx, n_tris, proj, view, NULL, amb, ldir, lcol, n_pl, plpos, plcol, cols, rows,
+                            rgba_out, depth_out, ids_out, uv8, atlas_rgba, atlas_w, atlas_h);
+}
+
+/*
+ * orc_render_textured with a model matrix (column-major binary32, or NULL for none): the mesh is drawn as if the
+ * vertex shader had a uModel uniform - see vertex_shader().  The reference's rasterizer has no model matrix; this
+ * is the definition the build's ar_set_model follows.
+ */
+int orc_render_model(const float *vbo9, uint32_t n_verts, const uint32_t *idx, uint32_t n_tris,
+                     const float *proj, const float *view, const float *model,
+                     const float *amb, const float *ldir, const float *lcol,
+                     int n_pl, const float *plpos, const float *plcol,
+                     int cols, int rows, uint8_t *rgba_out, float *depth_out, uint32_t *ids_out,
+                     const uint16_t *uv8, const uint8_t *atlas_rgba, int atlas_w, int atlas_h)
+{
     const orc_atlas atlas = { atlas_rgba, atlas_w, atlas_h };
     const int textured = uv8 && atlas_rgba && atlas_w > 1 && atlas_h > 1;
     if (cols <= 0 || rows <= 0 || n_pl < 0 || n_pl > ORC_MAX_POINT_LIGHTS) return -1;
@@ -327,13 +362,18 @@ int orc_render_textured(const float *vbo9, uint32_t n_verts, const uint32_t *idx
 
     float PV[16];
     orc_matmul_pv(proj, view, PV);
+    if (model) {                                    /* (P*V)*M, the same product routine */
+        float PVM[16];
+        orc_matmul_pv(PV, model, PVM);
+        memcpy(PV, PVM, sizeof PV);
+    }
     for (uint32_t t = 0; t < n_tris; t++) {
         const uint32_t i0 = idx[3 * t], i1 = idx[3 * t + 1], i2 = idx[3 * t + 2];
         if (i0 >= n_verts || i1 >= n_verts || i2 >= n_verts) continue;
         orc_vert in[3], sub[2][3];
-        vertex_shader(PV, vbo9 + (size_t)i0 * 9, &in[0]);
-        vertex_shader(PV, vbo9 + (size_t)i1 * 9, &in[1]);
-        vertex_shader(PV, vbo9 + (size_t)i2 * 9, &in[2]);
+        vertex_shader(PV, model, vbo9 + (size_t)i0 * 9, &in[0]);
+        vertex_shader(PV, model, vbo9 + (size_t)i1 * 9, &in[1]);
+        vertex_shader(PV, model, vbo9 + (size_t)i2 * 9, &in[2]);
         const int sample = textured && (uv8[8 * (size_t)t + 6] & 1u);
         if (sample)
             for (int k = 0; k < 3; k++) {

@@ -38,6 +38,8 @@ def lib():
         L.orc_render.restype = ctypes.c_int
         L.orc_render_textured.argtypes = L.orc_render.argtypes + [ctypes.POINTER(ctypes.c_uint16), u8p, ctypes.c_int, ctypes.c_int]
         L.orc_render_textured.restype = ctypes.c_int
+        L.orc_render_model.argtypes = L.orc_render.argtypes[:6] + [fp] + L.orc_render.argtypes[6:] + [ctypes.POINTER(ctypes.c_uint16), u8p, ctypes.c_int, ctypes.c_int]
+        L.orc_render_model.restype = ctypes.c_int
         L.orc_quantize.argtypes = [u8p, ctypes.c_int, ctypes.c_int, u8p, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, u8p]
         L.orc_quantize.restype = ctypes.c_int
@@ -58,13 +60,14 @@ def matmul_pv(proj, view):
     return out
 
 
-def render(vbo9, idx, proj, view, lights, cols, rows, want_ids=True, uv8=None, atlas=None):
+def render(vbo9, idx, proj, view, lights, cols, rows, want_ids=True, uv8=None, atlas=None, model=None):
     """Returns (rgba[rows,cols,4] u8, depth[rows,cols] f32, ids[rows,cols] u32), all top-down.
 
     lights: dict with 'ambient', 'dir', 'dir_color' (3 floats each) and 'pl_pos', 'pl_col'
     (n x 3 each, n <= 8).
     uv8: optional uint16 [n_tris, 8] (u0, v0, u1, v1, u2, v2, flags, 0); atlas: optional uint8 [h, w, 4]
     as handed to texImage2D.  Both given: atlas texturing.
+    model: optional column-major 4x4 model matrix (the vertex shader then has a uModel uniform).
     """
     vbo, vbop = _f(np.asarray(vbo9).reshape(-1))
     idx = np.ascontiguousarray(np.asarray(idx).reshape(-1), dtype=np.uint32)
@@ -88,13 +91,21 @@ def render(vbo9, idx, proj, view, lights, cols, rows, want_ids=True, uv8=None, a
             rgba.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
             depth.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
             ids.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)) if want_ids else None]
+    tex = [None, None, 0, 0]
     if uv8 is not None and atlas is not None:
         uv8 = np.ascontiguousarray(uv8, dtype=np.uint16).reshape(-1, 8)
         atlas = np.ascontiguousarray(atlas, dtype=np.uint8)
         if uv8.shape[0] != n_tris or atlas.ndim != 3 or atlas.shape[2] != 4:
             raise ValueError("uv8 must be [n_tris, 8] and atlas [h, w, 4]")
-        rc = lib().orc_render_textured(*args, uv8.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)),
-                                       atlas.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), atlas.shape[1], atlas.shape[0])
+        tex = [uv8.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), atlas.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+               atlas.shape[1], atlas.shape[0]]
+    if model is not None:
+        _m, mp = _f(np.asarray(model).reshape(-1))
+        if _m.size != 16:
+            raise ValueError("model must have 16 elements")
+        rc = lib().orc_render_model(*(args[:6] + [mp] + args[6:] + tex))
+    elif tex[0] is not None:
+        rc = lib().orc_render_textured(*(args + tex))
     else:
         rc = lib().orc_render(*args)
     if rc != 0:

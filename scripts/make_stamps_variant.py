@@ -14,10 +14,11 @@ rep("namespace {\n\nconstexpr uint64_t kBackgroundKey", "__device__ unsigned lon
 
 rep("    for (int c = int(tid); c < kTileCells; c += 256) keys[c] = kBackgroundKey;\n    if (tid == 0) { n_list = 0; n_big = 0; n_cov = 0; }", "    STAMP(0);\n    for (int c = int(tid); c < kTileCells; c += 256) keys[c] = kBackgroundKey;\n    if (tid == 0) { n_list = 0; n_big = 0; n_cov = 0; }")
 rep("        if (nl + 256 * kFilterBatch > uint32_t(kTileListMax) || last) {\n", "        if (nl + 256 * kFilterBatch > uint32_t(kTileListMax) || last) {\n            STAMP(1); if (tid == 0) g_stamps[blockIdx.x * 8 + 7] = nl;\n")
-rep("            __syncthreads();\n            // sweep list: the records are brought into LDS", "            __syncthreads();\n            STAMP(2);\n            // sweep list: the records are brought into LDS")
+rep("            __syncthreads();\n            // sweep list: the triangle records are brought into LDS", "            __syncthreads();\n            STAMP(2);\n            // sweep list: the triangle records are brought into LDS")
 rep("            __syncthreads();  // (every lane has read n_big by now)\n            if (tid == 0) { n_list = 0; n_big = 0; }", "            __syncthreads();\n            STAMP(3);\n            if (tid == 0) { n_list = 0; n_big = 0; }")
 rep("    __syncthreads();\n    const uint32_t nc = n_cov;", "    __syncthreads();\n    STAMP(4);\n    const uint32_t nc = n_cov;")
-rep("    __syncthreads();\n\n    // the tile's rows: 64 consecutive cells per row segment", "    __syncthreads();\n    STAMP(5);\n\n    // the tile's rows: 64 consecutive cells per row segment")
+rep("    __syncthreads();\n\n    // colour and ramp index of a resolved key", "    __syncthreads();\n    STAMP(5);\n\n    // colour and ramp index of a resolved key")
+rep("            reinterpret_cast<uint32_t *>(ridx)[cell >> 2] = ri4;\n        }\n        return;", "            reinterpret_cast<uint32_t *>(ridx)[cell >> 2] = ri4;\n        }\n        STAMP(6);\n        return;")
 # end of k_tile: find the closing of the output loop
 i = s.index("// ascii_stage.h")
 j = s.rindex("}\n}\n", 0, i)

@@ -38,13 +38,19 @@ def _clip_near(poly):
     return out
 
 
-def render(vbo9, idx, proj, view, lights, cols, rows):
+def render(vbo9, idx, proj, view, lights, cols, rows, model=None):
     """-> dict(rgba u8 [rows, cols, 4], depth f64 [rows, cols], covered bool, ambiguous bool), row 0 = top."""
     vbo = np.asarray(vbo9, dtype=np.float64).reshape(-1, 9)
     idx = np.asarray(idx, dtype=np.int64).reshape(-1, 3)
     P = np.asarray(proj, dtype=np.float64).reshape(4, 4).T      # column-major arrays -> matrices
     V = np.asarray(view, dtype=np.float64).reshape(4, 4).T
     PV = P @ V
+    if model is not None:
+        # a uModel uniform: clip = P V M p, world position = M p, normal = mat3(M) n
+        M = np.asarray(model, dtype=np.float64).reshape(4, 4).T
+        vbo = vbo.copy()
+        vbo[:, 0:3] = vbo[:, 0:3] @ M[:3, :3].T + M[:3, 3]
+        vbo[:, 3:6] = vbo[:, 3:6] @ M[:3, :3].T
     nv = vbo.shape[0]
     depth = np.ones((rows, cols))                                # GL window rows: j = 0 is the bottom
     second = np.ones((rows, cols))

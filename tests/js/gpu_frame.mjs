@@ -125,6 +125,25 @@ const dump = (name, ta) => fs.writeFileSync(path.join(outDir, name), Buffer.from
     tb.dispose();
   }
 
+  // a spinning cube: one setScene, then a model matrix per frame (setModelMatrix -> ar_set_model)
+  {
+    const hb = await import(path.join(JS, 'hip_backend.js'));
+    const sp = new hb.HipRasterBackend();
+    sp.setScene(sceneApi.meshScene(cube));
+    setCamera(cam.pos, cam.yaw, cam.pitch);
+    meta.spin = { cols: 80, rows: 40, cam, pixelAspect: config.PATH_TRACER.PIXEL_ASPECT, frames: [] };
+    for (let k = 0; k < 6; k++) {
+      const M = geometry.spinMatrix(2 * Math.PI * k / 6 + 0.1, [0.3, 1.0, 0.2], [0.1 * k, 0, 0], 1.0 + 0.05 * k);
+      sp.setModelMatrix(M);
+      const fb = new Uint8ClampedArray(80 * 40 * 4), state = { cols: 80, rows: 40, depth: new Float32Array(3200), ascii: new Uint8Array(3200) };
+      sp.render(0.0, fb, state);
+      dump('spin' + k + '.rgba', fb); dump('spin' + k + '.depth', state.depth); dump('spin' + k + '.ascii', state.ascii);
+      meta.spin.frames.push(Array.from(M));
+    }
+    sp.setModelMatrix(null);
+    sp.dispose();
+  }
+
   // the ray backend under the reference's names: router -> HipRaytraceBackend -> ar_rt_set_scene / ar_rt_render
   {
     const rtRef = JSON.parse(fs.readFileSync(path.join(here, '..', 'golden', 'ref_raytrace_uniforms.json'), 'utf8'));

@@ -27,7 +27,7 @@ def _check(pkg, oracle, R, sc, ramp="@%#*+=-:. ", mode=(True, 2, 12), label=""):
     pkg.scenes.upload(R, sc, ramp, *mode)
     out = R.render(sc["cols"], sc["rows"], want_ids=True)
     rgba, depth, ids = oracle.render(sc["vbo"], sc["idx"], sc["proj"], sc["view"], sc["lights"], sc["cols"], sc["rows"],
-                                     uv8=sc.get("uv8"), atlas=sc.get("atlas"))
+                                     uv8=sc.get("uv8"), atlas=sc.get("atlas"), model=sc.get("model"))
     ascii_ = oracle.quantize(rgba, sc["cols"], sc["rows"], ramp, int(mode[0]), mode[1], mode[2])
     name = label or sc["name"]
     assert np.array_equal(out["ids"], ids), "%s: %d cells differ in winner" % (name, np.count_nonzero(out["ids"] != ids))
@@ -167,6 +167,47 @@ def test_thousands_of_triangles_in_one_tile(pkg, oracle, R):
             _check(pkg, oracle, R, sc)
         if R.path_name == "tiled" and cols == 320:
             assert R.frame_counters()["bin_records"] > 3 * 2048      # (one bin holds nearly all of them)
+
+
+def test_spinning_cube_and_other_model_matrices(pkg, oracle, R, golden_dir):
+    """ar_set_model: C1's cube spun through sixty angles under a fixed camera (the mesh is uploaded once); a smooth,
+    point-lit icosphere scaled, turned, moved and pushed through the near plane; a soup of big triangles; a textured
+    scene; and back to no model matrix."""
+    sc = pkg.scenes.cube_scene(angle=0.6)
+    pkg.scenes.upload(R, sc)
+    covered = 0
+    for k in range(60):
+        M = pkg.geometry.spin_matrix(2 * math.pi * k / 60, axis=(0.3, 1.0, 0.2))
+        R.set_model(M)
+        out = R.render(80, 40, want_ids=True)
+        rgba, depth, ids = oracle.render(sc["vbo"], sc["idx"], sc["proj"], sc["view"], sc["lights"], 80, 40, model=M)
+        assert np.array_equal(out["ids"], ids) and np.array_equal(out["rgba"], rgba), "spin %d" % k
+        assert np.array_equal(out["depth"].view(np.uint32), depth.view(np.uint32)), "spin %d" % k
+        assert np.array_equal(out["ascii"], oracle.quantize(rgba, 80, 40, pkg.scenes.DEFAULT_RAMP, 1, 2, 12)), "spin %d" % k
+        covered += np.count_nonzero(ids != 0xFFFFFFFF)
+    assert covered > 60 * 100
+    sc = pkg.scenes.icosphere_scene(cols=333, rows=177, subdiv=4, point_lights=4)
+    for M in (pkg.geometry.spin_matrix(0.8, axis=(1.0, 0.2, -0.4), translate=(0.4, 0.1, -0.3), scale=1.7),
+              pkg.geometry.spin_matrix(2.1, axis=(0.0, 0.3, 1.0), translate=(1.2, 0.5, 0.9), scale=0.6),
+              pkg.geometry.spin_matrix(-1.3, scale=40.0)):                      # the camera ends up inside the sphere
+        _check(pkg, oracle, R, dict(sc, model=M), label="icosphere under a model matrix")
+        _check(pkg, oracle, R, dict(sc, model=M), mode=(False, 2, 12))
+    rng = np.random.default_rng(9)
+    T = 1500
+    centre = rng.uniform(-6, 6, size=(T, 1, 3))
+    P = (centre + rng.uniform(-1, 1, size=(T, 3, 3)) * rng.choice([0.05, 0.5, 4.0, 30.0], size=(T, 1, 1))).reshape(-1, 3)
+    vbo, idx = pkg.host.mesh_to_vbo(P.astype(np.float32), np.arange(T * 3).reshape(-1, 3), rng.uniform(0, 1, size=(T, 3)))
+    proj, view = pkg.host.camera_matrices({"pos": (0.1, 0.2, 0.3), "yaw": 0.7, "pitch": -0.2}, 200, 100, 0.5)
+    lights = pkg.host.pack_lights({"lights": {"points": [{"p": [1, 2, 0], "color": [1, 1, 1], "intensity": 4}]}})
+    M = pkg.geometry.spin_matrix(0.5, axis=(0.2, 0.1, 1.0), translate=(0.3, -0.2, 0.1), scale=0.8)
+    _check(pkg, oracle, R, {"name": "soup under a model matrix", "vbo": vbo, "idx": idx, "proj": proj, "view": view, "lights": lights,
+                            "cols": 200, "rows": 100, "model": M})
+    scene, tvbo, tidx, uv8, atlas = _textured_case(golden_dir, pkg, "default_scene_atlas32")
+    proj, view = pkg.host.camera_matrices({"pos": (0.0, 2.5, 6.0), "yaw": -math.pi / 2, "pitch": 0.0}, 120, 50, 0.5)
+    M = pkg.geometry.spin_matrix(0.3, axis=(0.0, 1.0, 0.1), translate=(0.2, 0.0, -0.5))
+    _check(pkg, oracle, R, {"name": "textured under a model matrix", "vbo": tvbo, "idx": tidx, "uv8": uv8, "atlas": atlas, "proj": proj,
+                            "view": view, "lights": pkg.host.pack_lights(scene), "cols": 120, "rows": 50, "model": M})
+    _check(pkg, oracle, R, pkg.scenes.icosphere_scene(angle=0.3, cols=160, rows=60, subdiv=2))     # (upload removes the matrix)
 
 
 def test_near_plane_and_huge_triangles(pkg, oracle, R):

@@ -87,6 +87,21 @@ def test_node_harness_frames_match_oracle(pkg, oracle, tmp_path, rt_uniforms_of)
     # (sphere vertices come from libm sin/cos, which V8 and glibc may round differently in the last place)
     assert np.mean(got_plain == plain) > 0.999 and np.all(got_plain[..., 3] == 255)
 
+    # a cube spun by model matrices built in JavaScript: the same matrices through the Python twin and the oracle
+    spin = meta["spin"]
+    vbo, idx = pkg.host.mesh_to_vbo(*pkg.geometry.cube(0.5))
+    proj, view = pkg.host.camera_matrices(spin["cam"], spin["cols"], spin["rows"], spin["pixelAspect"])
+    for k, M in enumerate(spin["frames"]):
+        M = np.asarray(M, dtype=np.float32)
+        want = pkg.geometry.spin_matrix(2 * np.pi * k / 6 + 0.1, (0.3, 1.0, 0.2), (0.1 * k, 0, 0), 1.0 + 0.05 * k)
+        assert np.allclose(M, want, atol=1e-6)
+        rgba, depth, _ = oracle.render(vbo, idx, proj, view, pkg.host.pack_lights({}), spin["cols"], spin["rows"], model=M)
+        assert np.array_equal(np.fromfile(tmp_path / ("spin%d.rgba" % k), dtype=np.uint8).reshape(rgba.shape), rgba), k
+        assert np.array_equal(np.fromfile(tmp_path / ("spin%d.depth" % k), dtype=np.float32).view(np.uint32), depth.view(np.uint32).reshape(-1)), k
+        assert np.array_equal(np.fromfile(tmp_path / ("spin%d.ascii" % k), dtype=np.uint8).reshape(depth.shape),
+                              oracle.quantize(rgba, spin["cols"], spin["rows"], ramp, 1, 2, 12)), k
+        assert np.count_nonzero(depth < 1.0) > 100
+
     # the ray backend through the router: same image as the oracle fed with the reference's recorded uniforms
     rtm = meta["raytrace"]
     with open(os.path.join(ROOT, "tests", "golden", "ref_raytrace_uniforms.json")) as fh:

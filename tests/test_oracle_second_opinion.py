@@ -20,8 +20,10 @@ from independent_raster import render as independent_render
 
 
 def _compare(oracle, sc, min_covered, max_ambiguous=0.05):
-    rgba, depth, ids = oracle.render(sc["vbo"], sc["idx"], sc["proj"], sc["view"], sc["lights"], sc["cols"], sc["rows"])
-    ind = independent_render(sc["vbo"], sc["idx"], sc["proj"], sc["view"], sc["lights"], sc["cols"], sc["rows"])
+    rgba, depth, ids = oracle.render(sc["vbo"], sc["idx"], sc["proj"], sc["view"], sc["lights"], sc["cols"], sc["rows"],
+                                     model=sc.get("model"))
+    ind = independent_render(sc["vbo"], sc["idx"], sc["proj"], sc["view"], sc["lights"], sc["cols"], sc["rows"],
+                             model=sc.get("model"))
     covered = ids != 0xFFFFFFFF
     clear = ~ind["ambiguous"]
     assert covered.sum() >= min_covered
@@ -74,6 +76,39 @@ def test_smooth_normals_and_reference_default_scene(pkg, oracle):
         seen += _compare(oracle, sc, 0, max_ambiguous=0.8)
         done += 1
     assert done >= 2 and seen > 500
+
+
+def test_model_matrix_matches_the_independent_renderer(pkg, oracle):
+    """The uModel definition of orc_render_model: the cube of C1 spun about a tilted axis under a fixed camera,
+    and a lit icosphere scaled, turned and pushed towards the camera until the near plane cuts it."""
+    total = 0
+    for k in range(0, 60, 4):
+        sc = pkg.scenes.cube_scene(angle=0.6)
+        sc["model"] = pkg.geometry.spin_matrix(2 * math.pi * k / 60, axis=(0.3, 1.0, 0.2))
+        total += _compare(oracle, sc, 100)
+    assert total > 15 * 100
+    sc = pkg.scenes.icosphere_scene(cols=200, rows=100, subdiv=3, point_lights=3)
+    sc["model"] = pkg.geometry.spin_matrix(0.8, axis=(1.0, 0.2, -0.4), translate=(0.4, 0.1, -0.3), scale=1.7)
+    _compare(oracle, sc, 3000)
+    # triangles of every size around and through the camera, so that the near plane cuts moved geometry
+    rng = np.random.default_rng(9)
+    T = 700
+    centre = rng.uniform(-6, 6, size=(T, 1, 3))
+    P = (centre + rng.uniform(-1, 1, size=(T, 3, 3)) * rng.choice([0.05, 0.5, 4.0, 30.0], size=(T, 1, 3))).reshape(-1, 3)
+    vbo, idx = pkg.host.mesh_to_vbo(P.astype(np.float32), np.arange(T * 3).reshape(-1, 3), rng.uniform(0, 1, size=(T, 3)))
+    proj, view = pkg.host.camera_matrices({"pos": (0.1, 0.2, 0.3), "yaw": 0.7, "pitch": -0.2}, 160, 80, 0.5)
+    lights = pkg.host.pack_lights({"lights": {"points": [{"p": [1, 2, 0], "color": [1, 1, 1], "intensity": 4}]}})
+    soup = {"name": "soup under a model matrix", "vbo": vbo, "idx": idx, "proj": proj, "view": view, "lights": lights, "cols": 160, "rows": 80,
+            "model": pkg.geometry.spin_matrix(0.5, axis=(0.2, 0.1, 1.0), translate=(0.3, -0.2, 0.1), scale=0.8)}
+    _compare(oracle, soup, 160 * 80 // 2)
+    ids = oracle.render(vbo, idx, proj, view, lights, 160, 80, model=soup["model"])[2]
+    assert np.count_nonzero((ids != 0xFFFFFFFF) & ((ids & 1) == 1)) > 50        # second halves of clipped triangles are on screen
+    # an identity model matrix changes nothing, bit for bit
+    sc = pkg.scenes.icosphere_scene(cols=160, rows=60, subdiv=2, point_lights=2)
+    a = oracle.render(sc["vbo"], sc["idx"], sc["proj"], sc["view"], sc["lights"], 160, 60)
+    b = oracle.render(sc["vbo"], sc["idx"], sc["proj"], sc["view"], sc["lights"], 160, 60, model=np.eye(4, dtype=np.float32).reshape(-1))
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
 
 
 def test_clip_soup_matches_the_independent_renderer(pkg, oracle):
