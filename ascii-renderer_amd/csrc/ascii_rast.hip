@@ -20,6 +20,7 @@
 // no fused multiply-add, correctly rounded division and square root) so that the output is
 // reproducible bit for bit; build with -ffp-contract=off.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <cmath>
 #include <cstdarg>
@@ -132,6 +133,7 @@ void ar_destroy(ar_ctx *ctx) {
     (void)hipFree(ctx->d_p_atlas); (void)hipFree(ctx->d_p_cov); (void)hipFree(ctx->d_p_image);
     (void)hipFree(ctx->d_state); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr); (void)hipFree(ctx->d_tri);
     (void)hipFree(ctx->d_triuv); (void)hipFree(ctx->d_atlas); (void)hipFree(ctx->d_rt);
+    (void)hipFree(ctx->d_tri_t); (void)hipFree(ctx->d_perm); (void)hipFree(ctx->d_box);
     for (int k = 0; k < kSets; k++) {
         (void)hipFree(ctx->d_entries[k]); (void)hipFree(ctx->d_surv[k]); (void)hipFree(ctx->d_sid[k]); (void)hipFree(ctx->d_surv_count[k]);
         (void)hipFree(ctx->d_dircount[k]);
@@ -217,7 +219,7 @@ int ar_set_mesh_uv(ar_ctx *ctx, const uint16_t *uv8, uint32_t n_tris) {
         AR_HIP(ctx, hipMalloc(&ctx->d_triuv, size_t(n_tris) * sizeof(uint4)));
         AR_HIP(ctx, hipMemcpy(ctx->d_triuv, uv8, size_t(n_tris) * sizeof(uint4), hipMemcpyHostToDevice));
     }
-    k_uvflags<<<(ctx->n_tris + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_triuv, ctx->n_tris, ctx->d_tri);
+    k_uvflags<<<(ctx->n_tris + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_triuv, ctx->d_perm, ctx->n_tris, ctx->d_tri, ctx->d_tri_t);
     AR_HIP(ctx, hipGetLastError());
     AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
@@ -780,6 +782,10 @@ int ar_set_option(ar_ctx *ctx, int option, long long value) {
         case AR_OPT_POOL_RECORDS:
             if (value < 0 || value > 0x7FFFFFFFll) return fail(ctx, AR_E_ARG, "AR_OPT_POOL_RECORDS out of range");
             ctx->pool_cap_option = uint32_t(value);
+            return 0;
+        case AR_OPT_TILE_ROWS:
+            if (value != 0 && value != 8 && value != 16 && value != 32) return fail(ctx, AR_E_ARG, "AR_OPT_TILE_ROWS takes 0, 8, 16 or 32");
+            ctx->tile_shift_option = value == 8 ? 3 : value == 16 ? 4 : value == 32 ? 5 : 0;
             return 0;
         default:
             return fail(ctx, AR_E_ARG, "unknown option %d", option);

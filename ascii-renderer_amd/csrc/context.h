@@ -45,11 +45,15 @@ struct ar_ctx {
     // tiled path
     int path = 0;                    // 0: tiled when the grid allows it, 1: always the direct path
     uint32_t pool_cap_option = 0;    // 0: sized from the triangle count
+    int tile_shift_option = 0;       // 0: tile height chosen per frame; 3, 4, 5: fixed at 8, 16, 32 rows
     float *d_tripos = nullptr;       // 9 planes x tripos_stride floats: triangle positions
     size_t tripos_stride = 0;
     float *d_triattr = nullptr;      // n_tris x 24 floats: the three vertices' normals and colours
     // everything the binning kernels write, per buffer set
-    TriStatic *d_tri = nullptr;      // n_tris 64-byte triangle records: positions, flat normal and colour, flags
+    TriStatic *d_tri = nullptr;      // n_tris 64-byte triangle records (positions, flat normal and colour, flags) in slot order
+    TriStatic *d_tri_t = nullptr;    // the same records in the order of the triangles' own indices (shading)
+    uint32_t *d_perm = nullptr;      // slot -> triangle index (the spatial order chosen at upload)
+    float *d_box = nullptr;          // bounding box of every block of 256 slots
     void *d_rt = nullptr;            // ray backend: the scene arrays of ar_rt_set_scene in one allocation
     RtScene rt_scene = {};           // counts and device pointers into d_rt
     bool rt_has_scene = false;
@@ -184,24 +188,53 @@ int drop_mesh(ar_ctx *ctx) {
     int rc = sync_streams(ctx);
     if (rc) return rc;
     (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr);
-    (void)hipFree(ctx->d_tri); (void)hipFree(ctx->d_triuv);
+    (void)hipFree(ctx->d_tri); (void)hipFree(ctx->d_triuv); (void)hipFree(ctx->d_tri_t); (void)hipFree(ctx->d_perm); (void)hipFree(ctx->d_box);
     ctx->d_vbo = nullptr; ctx->d_idx = nullptr; ctx->d_tripos = nullptr; ctx->d_triattr = nullptr;
     ctx->d_tri = nullptr; ctx->d_triuv = nullptr;  // texel coordinates belong to the mesh they were given for
+    ctx->d_tri_t = nullptr; ctx->d_perm = nullptr; ctx->d_box = nullptr;
     ctx->n_verts = 0; ctx->n_tris = 0;
     return 0;
 }
 
-// d_vbo / d_idx hold the new mesh: derive the streams of the tiled path (position planes, attribute rows,
-// triangle records).
+// d_vbo / d_idx hold the new mesh: choose the spatial order of its triangles (Morton code of the centroid, stable
+// radix sort) and derive the streams of the tiled path in that order (position planes, triangle records, block
+// boxes) plus the per-triangle copies the shading step reads (records, attribute rows).
 int finish_mesh(ar_ctx *ctx, uint32_t n_verts, uint32_t n_tris) {
     ctx->tripos_stride = (size_t(n_tris) + 63) / 64 * 64;
+    const size_t n_blocks = (size_t(n_tris) + 255) / 256;
     AR_HIP(ctx, hipMalloc(&ctx->d_tripos, 9 * ctx->tripos_stride * sizeof(float)));
     AR_HIP(ctx, hipMalloc(&ctx->d_triattr, size_t(n_tris) * 24 * sizeof(float)));
     AR_HIP(ctx, hipMalloc(&ctx->d_tri, size_t(n_tris) * sizeof(TriStatic)));
-    k_tristream<<<(n_tris + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_vbo, ctx->d_idx, n_verts, n_tris, ctx->tripos_stride, ctx->d_tripos,
-                                                              ctx->d_triattr, ctx->d_tri);
-    AR_HIP(ctx, hipGetLastError());
-    AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AR_HIP(ctx, hipMalloc(&ctx->d_tri_t, size_t(n_tris) * sizeof(TriStatic)));
+    AR_HIP(ctx, hipMalloc(&ctx->d_perm, size_t(n_tris) * sizeof(uint32_t)));
+    AR_HIP(ctx, hipMalloc(&ctx->d_box, n_blocks * 6 * sizeof(float)));
+    uint32_t *d_code = nullptr, *d_code_sorted = nullptr, *d_order = nullptr, *d_bounds = nullptr;
+    void *d_temp = nullptr;
+    auto sorted = [&]() -> int {
+        AR_HIP(ctx, hipMalloc(&d_code, size_t(n_tris) * sizeof(uint32_t)));
+        AR_HIP(ctx, hipMalloc(&d_code_sorted, size_t(n_tris) * sizeof(uint32_t)));
+        AR_HIP(ctx, hipMalloc(&d_order, size_t(n_tris) * sizeof(uint32_t)));
+        AR_HIP(ctx, hipMalloc(&d_bounds, 6 * sizeof(uint32_t)));
+        const uint32_t init[6] = {~0u, ~0u, ~0u, 0u, 0u, 0u};
+        AR_HIP(ctx, hipMemcpyAsync(d_bounds, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+        AR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (init lives on this stack frame)
+        const unsigned blocks = unsigned(n_blocks);
+        k_mesh_bounds<<<blocks < 2048u ? blocks : 2048u, 256, 0, ctx->stream>>>(ctx->d_vbo, ctx->d_idx, n_verts, n_tris, d_bounds);
+        k_morton<<<blocks, 256, 0, ctx->stream>>>(ctx->d_vbo, ctx->d_idx, n_verts, n_tris, d_bounds, d_code, d_order);
+        AR_HIP(ctx, hipGetLastError());
+        size_t temp_bytes = 0;
+        AR_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, d_code, d_code_sorted, d_order, ctx->d_perm, int(n_tris), 0, 30, ctx->stream));
+        AR_HIP(ctx, hipMalloc(&d_temp, temp_bytes ? temp_bytes : 1));
+        AR_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_code, d_code_sorted, d_order, ctx->d_perm, int(n_tris), 0, 30, ctx->stream));
+        k_tristream<<<blocks, 256, 0, ctx->stream>>>(ctx->d_vbo, ctx->d_idx, ctx->d_perm, n_verts, n_tris, ctx->tripos_stride, ctx->d_tripos,
+                                                     ctx->d_triattr, ctx->d_tri, ctx->d_tri_t, ctx->d_box);
+        AR_HIP(ctx, hipGetLastError());
+        AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return 0;
+    };
+    const int rc = sorted();
+    (void)hipFree(d_code); (void)hipFree(d_code_sorted); (void)hipFree(d_order); (void)hipFree(d_bounds); (void)hipFree(d_temp);
+    if (rc) return rc;
     ctx->n_verts = n_verts; ctx->n_tris = n_tris;
     return 0;
 }
@@ -250,7 +283,11 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
     const size_t strip_cells = size_t(fp.yb - fp.ya) * cols;
     const unsigned cell_blocks = unsigned((strip_cells + 255) / 256);
     fp.ntx = (cols + kTileW - 1) / kTileW;
-    fp.nty = (fp.yb - fp.ya + kTileH - 1) / kTileH;
+    // tile height: 32 rows, halved while the frame has fewer tiles than two per compute unit (strips, small grids)
+    fp.tshift = kTileShiftMax;
+    while (fp.tshift > kTileShiftMin && fp.ntx * (((fp.yb - fp.ya) + (1 << fp.tshift) - 1) >> fp.tshift) < 512) fp.tshift--;
+    if (ctx->tile_shift_option) fp.tshift = ctx->tile_shift_option;
+    fp.nty = ((fp.yb - fp.ya) + (1 << fp.tshift) - 1) >> fp.tshift;
     fp.bshift = 1;  // per-tile bins (0) shorten k_tile's filter but cost as much again in the binning kernels
     fp.nbx = (fp.ntx + (1 << fp.bshift) - 1) >> fp.bshift;
     fp.nby = (fp.nty + (1 << fp.bshift) - 1) >> fp.bshift;
@@ -337,7 +374,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
         uint32_t *blocksum = dircount + ctx->dircount_cap;
         {
             Stamper s(ctx, K_SETUP, fs);
-            k_setup<<<fp.n_groups, kSetupThreads, 0, fs>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_surv[set], ctx->d_sid[set],
+            k_setup<<<fp.n_groups, kSetupThreads, 0, fs>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_box, ctx->d_surv[set], ctx->d_sid[set],
                                                          ctx->d_surv_count[set], dircount);
         }
         {
@@ -352,9 +389,11 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
         {
             Stamper s(ctx, K_TILE, fs);
             const unsigned grid = unsigned((nbins + 7) / 8 * 8) << (2 * fp.bshift);
-            auto kernel = textured ? k_tile<true> : k_tile<false>;
+            auto kernel = fp.tshift == 5 ? (textured ? k_tile<true, 5> : k_tile<false, 5>)
+                          : fp.tshift == 4 ? (textured ? k_tile<true, 4> : k_tile<false, 4>)
+                                           : (textured ? k_tile<true, 3> : k_tile<false, 3>);
             kernel<<<grid, 256, 0, fs>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_triuv,
-                                         ctx->d_atlas, ctx->d_tri, ctx->d_entries[set], ctx->pool_cap, ctx->d_state,
+                                         ctx->d_atlas, ctx->d_tri, ctx->d_tri_t, ctx->d_entries[set], ctx->pool_cap, ctx->d_state,
                                          ctx->d_vis[set], ctx->d_rgba[oset], ctx->d_depth[oset], ascii_out, ctx->d_ridx[set],
                                          ctx->d_ids[oset]);
         }

@@ -34,6 +34,7 @@ struct FrameParams {
     int ntx, nty;    // tile grid over columns [0, cols) x output rows [ya, yb)
     int nbx, nby;    // bin grid
     int bshift;      // a bin is (1 << bshift)^2 tiles: 0 while the tiles fit the bin table, else 1
+    int tshift;      // log2 of the tile height in rows (5, 4 or 3)
     uint32_t chunk, n_groups;  // triangles per k_setup workgroup, number of those workgroups
     uint32_t frame;  // frame counter
     int set;         // buffer set of this frame (frame % kSets): binning state block, survivor slots, ...

@@ -5,8 +5,9 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// Tiled path: sub-triangles are binned to screen bins of 2x2 tiles, each 64x32-cell tile is resolved
-// in LDS.
+// Tiled path: sub-triangles are binned to screen bins of 2x2 tiles, each tile - 64 cells wide, 32 rows high, or
+// 16 or 8 when the frame (a strip, a small grid) would otherwise have too few tiles to fill the chip - is
+// resolved in LDS.
 //
 //   k_tristream (at mesh upload) gathers, per triangle, the three positions into nine planes of
 //             n_tris floats (36 contiguous, coalesced bytes per triangle for the per-frame pass),
@@ -41,12 +42,13 @@ namespace {
 // enqueue_frame.
 // ------------------------------------------------------------------------------------------------
 constexpr int kSets = 3;               // frames in flight: every per-frame buffer exists kSets times
-constexpr int kTileShiftH = 5;          // log2 of the tile height
-constexpr int kTileW = 64, kTileH = 1 << kTileShiftH, kTileCells = kTileW * kTileH;  // (a tile is one wavefront wide)
+constexpr int kTileW = 64;              // a tile is one wavefront wide ...
+constexpr int kTileShiftMax = 5, kTileShiftMin = 3;  // ... and 32, 16 or 8 rows high (FrameParams::tshift, chosen per frame)
 constexpr int kMaxTiles = 8000;       // tiles per frame the tiled path accepts
 constexpr int kMaxBins = 2048;        // >= kMaxTiles / 4 for any tile-grid shape the path accepts
 constexpr int kSetupThreads = 256;    // k_setup / k_fill workgroup size
 constexpr uint32_t kMaxGroups = 1024;  // k_setup workgroups (rows of the count table)
+constexpr int kMaxPasses = 512;        // passes of 256 slots a k_setup workgroup makes at most (2^27 triangles / 1024 / 256)
 constexpr int kTileBigMax = 512;      // per-tile list of triangles swept cooperatively
 constexpr int kTileStage = 64;        // of which so many are staged in LDS at a time (64 B each, in the cell list's 4 KB)
 constexpr int kTileSmallCells = 64;   // cell-range area (inside the tile) one lane scans itself
@@ -65,7 +67,7 @@ struct __align__(16) TriStatic {
     float p[9];      // positions of the three vertices
     float n[3];      // normal (flat triangles)
     float c[3];      // colour (flat triangles)
-    uint32_t flags;  // kFlagFlat | kFlagTextured
+    uint32_t flags;  // kFlagFlat | kFlagTextured in the low kFlagBits bits, the triangle's index t above them
 };
 static_assert(sizeof(TriStatic) == 64, "triangle records are four 16-byte loads");
 
@@ -125,48 +127,164 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_flags(bool h0, bool h1,
     return off + below;
 }
 
-// Per triangle: positions -> planes pos[k*stride + t] (k = 3*vertex + axis); normal and colour of each
-// vertex -> attr[t*24 + 8*v ..] = (nx, ny, nz, r, g, b, 0, 0), so a vertex is one 16-byte plus one
-// 8-byte load; tri[t] = the triangle's 64-byte record, kFlagFlat set when the three normals and the three
-// colours are identical.
-// A triangle that names a vertex outside the buffer gets NaN positions, which every later stage rejects.
-__global__ __launch_bounds__(256) void k_tristream(const float *__restrict__ vbo, const uint32_t *__restrict__ idx,
-                                                   uint32_t n_verts, uint32_t n_tris, size_t stride,
-                                                   float *__restrict__ pos, float *__restrict__ attr,
-                                                   TriStatic *__restrict__ tri) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= n_tris) return;
-    float a[3][9];
-    bool all_ok = true;
-#pragma unroll
+// ---- mesh streams in spatial order ------------------------------------------------------------------------
+// The per-frame pass walks the triangles in the order of their position planes, 256 at a time, and a tile fetches
+// the records of the triangles binned to it.  Both want triangles that are close in space to be close in memory:
+// a block of 256 consecutive triangles then touches few bins (long runs in every bin's entry array, and a tight
+// bounding box that lets whole blocks be skipped when they miss the view or the strip), and the records a tile
+// fetches share cache lines.  So at upload the triangles are sorted by the 30-bit Morton code of their centroid
+// inside the mesh's bounding box (a stable radix sort: equal codes keep submission order) and everything the
+// binning reads is laid out in that order, "slot" s = position in the sorted order.  Nothing a caller can see
+// depends on it: visibility keys, winner ids and the tie rule use the triangle's own index t, which every record
+// carries, and the shading step reads a second copy of the records kept in t order.
+
+constexpr int kFlagBits = 3;  // a record's flags word: kFlagFlat | kFlagTextured below, the triangle's index t above
+
+// float -> unsigned with the same order (for atomic min / max on coordinates)
+__device__ __forceinline__ uint32_t float_order(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float float_unorder(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// Centroid of triangle t (any finite triangle; others report false).
+__device__ __forceinline__ bool triangle_centroid(const float *__restrict__ vbo, const uint32_t *__restrict__ idx, uint32_t n_verts,
+                                                  uint32_t t, float (&c)[3]) {
+    c[0] = c[1] = c[2] = 0.0f;
     for (int v = 0; v < 3; v++) {
         const uint32_t vi = idx[3 * size_t(t) + v];
-        const bool ok = vi < n_verts;
-        all_ok = all_ok && ok;
-        const float *p = vbo + size_t(ok ? vi : 0u) * 9;
-#pragma unroll
-        for (int q = 0; q < 9; q++) a[v][q] = ok ? p[q] : 0.0f;
-#pragma unroll
-        for (int ax = 0; ax < 3; ax++) pos[size_t(3 * v + ax) * stride + t] = ok ? p[ax] : __builtin_nanf("");
+        if (vi >= n_verts) return false;
+        const float *p = vbo + size_t(vi) * 9;
+        for (int ax = 0; ax < 3; ax++) c[ax] += p[ax];
     }
-    float4 *row = reinterpret_cast<float4 *>(attr) + size_t(t) * 6;
-    bool is_flat = all_ok;
-#pragma unroll
-    for (int v = 0; v < 3; v++) {
-        row[2 * v] = make_float4(a[v][3], a[v][4], a[v][5], a[v][6]);
-        row[2 * v + 1] = make_float4(a[v][7], a[v][8], 0.0f, 0.0f);
-#pragma unroll
-        for (int q = 3; q < 9; q++) is_flat = is_flat && (__float_as_uint(a[v][q]) == __float_as_uint(a[0][q]));
+    for (int ax = 0; ax < 3; ax++) c[ax] *= (1.0f / 3.0f);
+    return isfinite(c[0]) && isfinite(c[1]) && isfinite(c[2]);
+}
+
+// bounds[0..2] = min, [3..5] = max of the centroids, as float_order keys (initialised to ~0 / 0 by the caller).
+__global__ __launch_bounds__(256) void k_mesh_bounds(const float *__restrict__ vbo, const uint32_t *__restrict__ idx,
+                                                     uint32_t n_verts, uint32_t n_tris, uint32_t *__restrict__ bounds) {
+    uint32_t lo[3] = {~0u, ~0u, ~0u}, hi[3] = {0u, 0u, 0u};
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n_tris; t += gridDim.x * 256u) {
+        float c[3];
+        if (!triangle_centroid(vbo, idx, n_verts, t, c)) continue;
+        for (int ax = 0; ax < 3; ax++) {
+            const uint32_t k = float_order(c[ax]);
+            lo[ax] = min(lo[ax], k); hi[ax] = max(hi[ax], k);
+        }
     }
-    TriStatic r;
+    for (int ax = 0; ax < 3; ax++) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            lo[ax] = min(lo[ax], uint32_t(__shfl_xor(int(lo[ax]), d)));
+            hi[ax] = max(hi[ax], uint32_t(__shfl_xor(int(hi[ax]), d)));
+        }
+        if ((threadIdx.x & 63u) == 0u) { atomicMin(&bounds[ax], lo[ax]); atomicMax(&bounds[3 + ax], hi[ax]); }
+    }
+}
+
+__device__ __forceinline__ uint32_t spread_bits_10(uint32_t v) {  // abcdefghij -> a00b00c00...j
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// code[t] = Morton code of triangle t's centroid in the box of k_mesh_bounds (0 for triangles without one), order[t] = t.
+__global__ __launch_bounds__(256) void k_morton(const float *__restrict__ vbo, const uint32_t *__restrict__ idx, uint32_t n_verts,
+                                                uint32_t n_tris, const uint32_t *__restrict__ bounds, uint32_t *__restrict__ code,
+                                                uint32_t *__restrict__ order) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_tris) return;
+    float c[3];
+    uint32_t m = 0;
+    if (triangle_centroid(vbo, idx, n_verts, t, c)) {
+        uint32_t q[3];
+        for (int ax = 0; ax < 3; ax++) {
+            const float lo = float_unorder(bounds[ax]), hi = float_unorder(bounds[3 + ax]);
+            const float ext = hi - lo;
+            const float u = (ext > 0.0f && isfinite(ext)) ? (c[ax] - lo) / ext : 0.0f;
+            q[ax] = uint32_t(fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f));
+        }
+        m = spread_bits_10(q[0]) | (spread_bits_10(q[1]) << 1) | (spread_bits_10(q[2]) << 2);
+    }
+    code[t] = m;
+    order[t] = t;
+}
+
+// Per slot s (perm[s] = t, the triangle in that place of the spatial order): positions -> planes pos[k*stride + s]
+// (k = 3*vertex + axis); tri_s[s] = the triangle's 64-byte record with t in the upper bits of its flags word and
+// kFlagFlat set when the three normals and the three colours are identical.  Per triangle t: the same record in
+// tri_t[t] (the shading step's copy) and the normal and colour of each vertex -> attr[t*24 + 8*v ..] = (nx, ny,
+// nz, r, g, b, 0, 0), so a vertex is one 16-byte plus one 8-byte load.  box[6 * (s / 256) ..] = bounding box
+// (min xyz, max xyz) of the positions of each block of 256 slots (NaN coordinates left out).
+// A triangle that names a vertex outside the buffer gets NaN positions, which every later stage rejects.
+__global__ __launch_bounds__(256) void k_tristream(const float *__restrict__ vbo, const uint32_t *__restrict__ idx,
+                                                   const uint32_t *__restrict__ perm, uint32_t n_verts, uint32_t n_tris,
+                                                   size_t stride, float *__restrict__ pos, float *__restrict__ attr,
+                                                   TriStatic *__restrict__ tri_s, TriStatic *__restrict__ tri_t,
+                                                   float *__restrict__ box) {
+    __shared__ float s_box[4][6];
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (s < n_tris) {
+        const uint32_t t = perm[s];
+        float a[3][9];
+        bool all_ok = true, okv[3];
 #pragma unroll
-    for (int v = 0; v < 3; v++)
+        for (int v = 0; v < 3; v++) {
+            const uint32_t vi = idx[3 * size_t(t) + v];
+            const bool ok = vi < n_verts;
+            okv[v] = ok;
+            all_ok = all_ok && ok;
+            const float *p = vbo + size_t(ok ? vi : 0u) * 9;
 #pragma unroll
-        for (int ax = 0; ax < 3; ax++) r.p[3 * v + ax] = all_ok || idx[3 * size_t(t) + v] < n_verts ? a[v][ax] : __builtin_nanf("");
+            for (int q = 0; q < 9; q++) a[v][q] = ok ? p[q] : 0.0f;
 #pragma unroll
-    for (int q = 0; q < 3; q++) { r.n[q] = a[0][3 + q]; r.c[q] = a[0][6 + q]; }
-    r.flags = is_flat ? kFlagFlat : 0u;
-    tri[t] = r;
+            for (int ax = 0; ax < 3; ax++) {
+                const float x = ok ? p[ax] : __builtin_nanf("");
+                pos[size_t(3 * v + ax) * stride + s] = x;
+                lo[ax] = fminf(lo[ax], x); hi[ax] = fmaxf(hi[ax], x);  // (fminf / fmaxf drop a NaN operand)
+            }
+        }
+        float4 *row = reinterpret_cast<float4 *>(attr) + size_t(t) * 6;
+        bool is_flat = all_ok;
+#pragma unroll
+        for (int v = 0; v < 3; v++) {
+            row[2 * v] = make_float4(a[v][3], a[v][4], a[v][5], a[v][6]);
+            row[2 * v + 1] = make_float4(a[v][7], a[v][8], 0.0f, 0.0f);
+#pragma unroll
+            for (int q = 3; q < 9; q++) is_flat = is_flat && (__float_as_uint(a[v][q]) == __float_as_uint(a[0][q]));
+        }
+        TriStatic r;
+#pragma unroll
+        for (int v = 0; v < 3; v++)
+#pragma unroll
+            for (int ax = 0; ax < 3; ax++) r.p[3 * v + ax] = okv[v] ? a[v][ax] : __builtin_nanf("");
+#pragma unroll
+        for (int q = 0; q < 3; q++) { r.n[q] = a[0][3 + q]; r.c[q] = a[0][6 + q]; }
+        r.flags = (is_flat ? kFlagFlat : 0u) | (t << kFlagBits);
+        tri_s[s] = r;
+        tri_t[t] = r;
+    }
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++)
+        for (int d = 32; d >= 1; d >>= 1) {
+            lo[ax] = fminf(lo[ax], __shfl_xor(lo[ax], d));
+            hi[ax] = fmaxf(hi[ax], __shfl_xor(hi[ax], d));
+        }
+    if ((threadIdx.x & 63u) == 0u)
+        for (int ax = 0; ax < 3; ax++) { s_box[threadIdx.x >> 6][ax] = lo[ax]; s_box[threadIdx.x >> 6][3 + ax] = hi[ax]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = int(threadIdx.x);
+        float v = s_box[0][k];
+        for (int w = 1; w < 4; w++) v = k < 3 ? fminf(v, s_box[w][k]) : fmaxf(v, s_box[w][k]);
+        box[size_t(blockIdx.x) * 6 + k] = v;
+    }
 }
 
 // Indexed mesh -> the reference's unshared, flat-shaded vertex buffer (what _rebuildGeometry's pushTri emits
@@ -205,13 +323,17 @@ __global__ __launch_bounds__(256) void k_build_vbo(const float *__restrict__ pos
     }
 }
 
-// Copies the "sample the atlas" bit of every triangle's texel-coordinate row into its flag byte (all bits
-// cleared when triuv is null).
-__global__ __launch_bounds__(256) void k_uvflags(const uint4 *__restrict__ triuv, uint32_t n_tris, TriStatic *__restrict__ tri) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= n_tris) return;
+// Copies the "sample the atlas" bit of every triangle's texel-coordinate row into the flags word of both of its
+// records (cleared when triuv is null).  One lane per slot.
+__global__ __launch_bounds__(256) void k_uvflags(const uint4 *__restrict__ triuv, const uint32_t *__restrict__ perm, uint32_t n_tris,
+                                                 TriStatic *__restrict__ tri_s, TriStatic *__restrict__ tri_t) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= n_tris) return;
+    const uint32_t t = perm[s];
     const bool sample = triuv && (triuv[t].w & kUvSample) != 0u;
-    tri[t].flags = (tri[t].flags & ~kFlagTextured) | (sample ? kFlagTextured : 0u);
+    const uint32_t f = (tri_s[s].flags & ~kFlagTextured) | (sample ? kFlagTextured : 0u);
+    tri_s[s].flags = f;
+    tri_t[t].flags = f;
 }
 
 template <typename FP>
@@ -227,7 +349,7 @@ __device__ __forceinline__ Vert<0> transform_position(const FP &fp, float x, flo
 __device__ __forceinline__ void bin_range(const FrameParams &fp, int i0, int i1, int j0, int j1, int &bx0, int &bx1,
                                           int &by0, int &by1) {
     bx0 = i0 >> (6 + fp.bshift); bx1 = i1 >> (6 + fp.bshift);
-    by0 = (fp.rows - 1 - j1 - fp.ya) >> (kTileShiftH + fp.bshift); by1 = (fp.rows - 1 - j0 - fp.ya) >> (kTileShiftH + fp.bshift);
+    by0 = (fp.rows - 1 - j1 - fp.ya) >> (fp.tshift + fp.bshift); by1 = (fp.rows - 1 - j0 - fp.ya) >> (fp.tshift + fp.bshift);
 }
 
 // One sub-triangle that survived setup: screen-space vertices and inclusive cell range.
@@ -297,29 +419,64 @@ __device__ __forceinline__ bool sub_triangle_screen(const FrameParams &fp, const
     return sub ? to_screen(s1[0].c, s1[1].c, s1[2].c, fp.hw, fp.hh, sc) : to_screen(s0[0].c, s0[1].c, s0[2].c, fp.hw, fp.hh, sc);
 }
 
-// Workgroup g owns survivor slots [g * 2 * chunk, (g + 1) * 2 * chunk) and fills them densely, in triangle
-// order.  surv: the cell range of a survivor, (i0 | i1 << 16, j0 | j1 << 16); sid: its id 2*triangle + sub -
+// Workgroup g owns survivor places [g * 2 * chunk, (g + 1) * 2 * chunk) and fills them densely, in the order it
+// meets the survivors.  surv: the cell range of a survivor, (i0 | i1 << 16, j0 | j1 << 16); sid: 2*slot + sub -
 // all k_fill needs.  Nothing else of the setup is kept: the tiles redo it from the triangle records.
-// One triangle per lane and pass; chunk is a multiple of the workgroup size (one pass up to about
-// four million triangles).
+// One triangle per lane and pass; chunk (a multiple of the workgroup size) bounds the passes of a workgroup.
 __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const float *__restrict__ tripos, size_t stride,
-                                                         uint2 *__restrict__ surv, uint32_t *__restrict__ sid,
-                                                         uint32_t *__restrict__ surv_count, uint32_t *__restrict__ dircount) {
+                                                         const float *__restrict__ box, uint2 *__restrict__ surv,
+                                                         uint32_t *__restrict__ sid, uint32_t *__restrict__ surv_count,
+                                                         uint32_t *__restrict__ dircount) {
     __shared__ uint32_t hist[kMaxBins];
     __shared__ uint32_t s_wave[kSetupThreads / 64];
+    __shared__ uint32_t outside[kMaxPasses];  // per pass: the frustum planes that all eight corners of its box lie beyond
     const uint32_t tid = threadIdx.x;
     const int nbins = fp.nbx * fp.nby;
-    const uint32_t t_begin = blockIdx.x * fp.chunk;
-    const uint32_t t_end = min(t_begin + fp.chunk, fp.n_tris);
+    // Blocks of 256 slots are dealt to the workgroups round-robin (block p goes to workgroup p mod n_groups): the
+    // slots are in spatial order, so a view or a strip that shows only part of the mesh leaves every workgroup
+    // with about the same share of blocks that are not skipped below.
+    const uint32_t total_pass = (fp.n_tris + kSetupThreads - 1) / kSetupThreads;
+    const uint32_t n_pass = blockIdx.x < total_pass ? (total_pass - blockIdx.x + fp.n_groups - 1) / fp.n_groups : 0u;
     for (int k = int(tid); k < nbins; k += kSetupThreads) hist[k] = 0;
+    for (uint32_t k = tid; k < n_pass; k += kSetupThreads) outside[k] = 0x3Fu;
     __syncthreads();
     const int jlo = fp.rows - fp.yb, jhi = fp.rows - 1 - fp.ya;
+    // Which passes can be skipped: a pass covers one block of 256 slots, whose bounding box was taken at upload.
+    // One lane per (pass, corner) puts the corner through the vertex transform and tests it against the six planes
+    // that bound what this frame can show (columns -1 .. cols + 1, the strip's window rows widened by two, near,
+    // far); a plane that every corner lies beyond - by more than the rounding of these sums can account for - has
+    // the whole box, and every triangle in it, on its far side.
+    for (uint32_t q = tid; q < 8u * n_pass; q += kSetupThreads) {
+        const uint32_t pass = q >> 3;
+        const float *b = box + (size_t(pass) * fp.n_groups + blockIdx.x) * 6;
+        const float x = b[(q & 1u) ? 3 : 0], y = b[(q & 2u) ? 4 : 1], z = b[(q & 4u) ? 5 : 2];
+        float c[4], m[4];  // clip coordinates and the sums of the magnitudes of their terms
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            c[r] = ((fp.pv[0 * 4 + r] * x + fp.pv[1 * 4 + r] * y) + fp.pv[2 * 4 + r] * z) + fp.pv[3 * 4 + r];
+            m[r] = ((fabsf(fp.pv[0 * 4 + r] * x) + fabsf(fp.pv[1 * 4 + r] * y)) + fabsf(fp.pv[2 * 4 + r] * z)) + fabsf(fp.pv[3 * 4 + r]);
+        }
+        constexpr float kEps = 1.0f / 1048576.0f;  // 2^-20: eight times what four rounded terms can be off by
+        const float X = (c[0] + c[3]) * fp.hw, Y = (c[1] + c[3]) * fp.hh;
+        const float mx = (m[0] + m[3]) * fp.hw, my = (m[1] + m[3]) * fp.hh;
+        const float fj0 = float(jlo - 2), fj1 = float(jhi + 3), fc = float(fp.cols + 1);
+        uint32_t o = 0;
+        o |= (X + c[3] < -kEps * (mx + m[3])) ? 1u : 0u;                              // left of column -1
+        o |= (fc * c[3] - X < -kEps * (mx + fc * m[3])) ? 2u : 0u;                     // right of column cols + 1
+        o |= (Y - fj0 * c[3] < -kEps * (my + fabsf(fj0) * m[3])) ? 4u : 0u;            // below the strip's rows
+        o |= (fj1 * c[3] - Y < -kEps * (my + fabsf(fj1) * m[3])) ? 8u : 0u;            // above them
+        o |= (c[2] + c[3] < -kEps * (m[2] + m[3])) ? 16u : 0u;                         // behind the near plane
+        o |= (c[3] - c[2] < -kEps * (m[2] + m[3])) ? 32u : 0u;                         // beyond the far plane
+        atomicAnd(&outside[pass], o);
+    }
+    __syncthreads();
     const uint32_t loc_base = blockIdx.x * 2u * fp.chunk;
     uint32_t run = 0;  // slots handed out so far (identical in every lane)
 
-    for (uint32_t tb = t_begin; tb < t_end; tb += kSetupThreads) {
-        const uint32_t t = tb + tid;
-        const bool live = t < t_end;
+    for (uint32_t pass = 0; pass < n_pass; pass++) {
+        if (outside[pass] != 0u) continue;  // (the same in every lane of the workgroup)
+        const uint32_t t = (pass * fp.n_groups + blockIdx.x) * kSetupThreads + tid;  // the slot: position in the spatial order
+        const bool live = t < fp.n_tris;
         Candidate c[2];
         bool have[2] = {false, false}, clipped = false;
         if (live) {
@@ -452,10 +609,10 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Tr
     for (uint32_t s = tid; s < n; s += kSetupThreads) {
         const uint32_t loc = loc_base + s;
         const uint2 sv = surv[loc];
-        const uint32_t id = sid[loc];  // 2*triangle + sub: what entries and visibility keys carry
+        const uint32_t id = sid[loc];  // 2*slot + sub: what the entries carry
         const int i0 = int(sv.x & 0xFFFFu), i1 = int(sv.x >> 16), j0 = int(sv.y & 0xFFFFu), j1 = int(sv.y >> 16);
         const int r0 = fp.rows - 1 - j1 - fp.ya, r1 = fp.rows - 1 - j0 - fp.ya;  // rows relative to the strip
-        const int tx0 = i0 >> 6, tx1 = i1 >> 6, ty0 = r0 >> kTileShiftH, ty1 = r1 >> kTileShiftH;
+        const int tx0 = i0 >> 6, tx1 = i1 >> 6, ty0 = r0 >> fp.tshift, ty1 = r1 >> fp.tshift;
         int bx0, bx1, by0, by1;
         bin_range(fp, i0, i1, j0, j1, bx0, bx1, by0, by1);
         bool direct = false;
@@ -474,6 +631,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Tr
             }
         if (direct) {  // a bin it touches has no room: resolve through the global key buffer
             const TriStatic ts = tri[id >> 1];
+            const uint32_t key_id = 2u * (ts.flags >> kFlagBits) + (id & 1u);  // keys carry the triangle's own index
             Screen sc;
             bool clipped;
             if (!sub_triangle_screen(fp, ts.p, id & 1u, sc, clipped)) continue;
@@ -483,7 +641,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Tr
                 const size_t row = size_t(fp.rows - 1 - j) * fp.cols;
                 for (int i = i0; i <= i1; i++) {
                     float f[3], zw;
-                    if (cover(e, i, j, f, zw)) vis_min(vis, row + i, make_key(zw, tile_key_low(id, clipped)));
+                    if (cover(e, i, j, f, zw)) vis_min(vis, row + i, make_key(zw, tile_key_low(key_id, clipped)));
                 }
             }
         }

@@ -244,21 +244,23 @@ __device__ __forceinline__ void raster_range(const FrameParams &fp, const Edges 
     }
 }
 
-// TEX: the frame samples an atlas (texel coordinates and atlas are only read then).
-template <bool TEX>
+// TEX: the frame samples an atlas (texel coordinates and atlas are only read then).  SH: log2 of the tile height.
+template <bool TEX, int SH>
 __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__restrict__ vbo,
                                               const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
                                               const uint4 *__restrict__ triuv, const uint32_t *__restrict__ atlas,
-                                              const TriStatic *__restrict__ tri,
+                                              const TriStatic *__restrict__ tri, const TriStatic *__restrict__ tri_t,
                                               const uint32_t *__restrict__ entries, uint32_t entries_cap,
                                               const BinState *__restrict__ state, uint64_t *__restrict__ vis,
                                               uint8_t *__restrict__ rgba, float *__restrict__ depth,
                                               uint8_t *__restrict__ ascii, uint8_t *__restrict__ ridx,
                                               uint32_t *__restrict__ ids) {
+    constexpr int kTileH = 1 << SH, kTileCells = kTileW * kTileH;
     __shared__ uint64_t keys[kTileCells];
     __shared__ uint32_t list[kTileListMax];
     __shared__ uint32_t big[kTileBigMax];
-    __shared__ __align__(16) uint16_t covered[kTileCells];  // covered cells for the shading step; before that, staging for swept records
+    // covered cells for the shading step; before that, staging for kTileStage swept records of 64 bytes
+    __shared__ __align__(16) uint16_t covered[kTileCells > kTileStage * 32 ? kTileCells : kTileStage * 32];
     __shared__ uint32_t n_list, n_big, n_cov;
     const uint32_t tid = threadIdx.x;
     // Workgroups are handed to the eight XCDs round-robin and each XCD has its own L2: the tiles of one
@@ -305,28 +307,46 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
         const bool last = eb + 256 * kFilterBatch >= e_end;
         if (nl + 256 * kFilterBatch > uint32_t(kTileListMax) || last) {
             // sub-triangles with a small cell range inside the tile: one lane each; others -> sweep list
-            // (a lane's next triangle record is fetched while it works on the current one)
+            // (a lane's next triangle record is fetched while it works on the current one).
+            // A short list leaves most lanes without a triangle, and the few that have one walk their rows one
+            // after the other: then 2, 4, 8 or 16 neighbouring lanes share a triangle - each redoes its setup (for
+            // nothing: the wavefront executes those instructions anyway) and takes an equal share of its rows.
+            int gshift = 0;
+            while (gshift < 4 && (nl << (gshift + 1)) <= 256u) gshift++;
+            const uint32_t per_round = 256u >> gshift, first = tid >> gshift;
+            const int part = int(tid & ((1u << gshift) - 1u));
             TriStatic ahead;
-            if (tid < nl) ahead = tri[list[tid] >> 1];
-            for (uint32_t r = tid; r < nl; r += 256) {
+            if (first < nl) ahead = tri[list[first] >> 1];
+            for (uint32_t r = first; r < nl; r += per_round) {
                 const uint32_t id = list[r];
                 const TriStatic ts = ahead;
-                if (r + 256 < nl) ahead = tri[list[r + 256] >> 1];
+                if (r + per_round < nl) ahead = tri[list[r + per_round] >> 1];
                 Screen sc;
                 bool clipped;
                 int ci0, ci1, cj0, cj1;
                 binned_triangle_screen(fp, ts.p, id & 1u, sc, clipped);
                 if (!cell_range(sc.X, sc.Y, sc.W, fp.cols, jlo, jhi, ci0, ci1, cj0, cj1)) continue;  // (binned: never empty)
                 const int i0 = max(ci0, tx0), i1 = min(ci1, tx1);
-                const int r0 = max(fp.rows - 1 - cj1, tr0), r1 = min(fp.rows - 1 - cj0, tr1);
-                if ((i1 - i0 + 1) * (r1 - r0 + 1) > kTileSmallCells) {
-                    const uint32_t slot = atomicAdd(&n_big, 1u);
-                    if (slot < uint32_t(kTileBigMax)) { big[slot] = id; continue; }
-                    // list full: this lane scans the range itself (slow but correct)
+                int r0 = max(fp.rows - 1 - cj1, tr0), r1 = min(fp.rows - 1 - cj0, tr1);
+                if ((i1 - i0 + 1) * (r1 - r0 + 1) > (kTileSmallCells << gshift)) {
+                    uint32_t slot = 0;
+                    if (part == 0) slot = atomicAdd(&n_big, 1u);
+                    slot = uint32_t(__shfl(int(slot), int(tid & 63u) & ~((1 << gshift) - 1)));  // the sharing lanes are neighbours in one wavefront
+                    if (slot < uint32_t(kTileBigMax)) {
+                        if (part == 0) big[slot] = id;
+                        continue;
+                    }
+                    // list full: these lanes scan the range themselves (slow but correct)
+                }
+                if (gshift) {  // this lane's share of the rows
+                    const int len = (r1 - r0 + (1 << gshift)) >> gshift;
+                    r0 += part * len;
+                    r1 = min(r0 + len - 1, r1);
+                    if (r0 > r1) continue;
                 }
                 Edges ed;
                 edges_from_screen(sc, ed);
-                raster_range(fp, ed, tile_key_low(id, clipped), i0, i1, r0, r1, tx0, tr0, keys);
+                raster_range(fp, ed, tile_key_low(2u * (ts.flags >> kFlagBits) + (id & 1u), clipped), i0, i1, r0, r1, tx0, tr0, keys);
             }
             __syncthreads();
             // sweep list: the triangle records are brought into LDS 64 at a time (one fetch latency per batch instead
@@ -339,6 +359,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
                 __syncthreads();
                 for (uint32_t q = tid >> 6; q < ns; q += 4) {
                     const uint32_t id = big[b0 + q];
+                    const uint32_t key_id = 2u * (stage[q].flags >> kFlagBits) + (id & 1u);
                     float p[9];
 #pragma unroll
                     for (int k = 0; k < 9; k++) p[k] = stage[q].p[k];
@@ -357,7 +378,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
                         float f[3], zw;
                         if (cover(ed, i, fp.rows - 1 - rr, f, zw))
                             atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
-                                      (unsigned long long)make_key(zw, tile_key_low(id, clipped)));
+                                      (unsigned long long)make_key(zw, tile_key_low(key_id, clipped)));
                     }
                 }
                 __syncthreads();
@@ -394,7 +415,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
         const int rr = tr0 + (c >> 6), i = tx0 + (c & 63);
         const uint32_t low = uint32_t(keys[c]);  // the key's low word is the winner: (2*triangle + sub) << 1 | clipped
         const uint32_t id = low >> 1;
-        const TriStatic ts = tri[id >> 1];
+        const TriStatic ts = tri_t[id >> 1];  // (the winner is known by its own index: the copy kept in that order)
         uint8_t px[4];
         shade_from_triangle<TEX>(fp, *kernarg_params(), vbo, idx, triattr, triuv, atlas, ts, id, (low & 1u) != 0u, i, fp.rows - 1 - rr, px);
         if (fp.want_ids) ids[size_t(rr) * fp.cols + i] = id;

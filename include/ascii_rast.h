@@ -256,17 +256,20 @@ int ar_frame_counters(ar_ctx *ctx, uint32_t out[8]);
 
 /* Tuning / test switches (no counterpart in the reference).
  *   AR_OPT_PATH          0 (default): tile-binned path whenever the grid has at most 8000 tiles of
- *                        64x32 cells, else the direct path; 1: always the direct path (every
+ *                        64 cells by the frame's tile height, else the direct path; 1: always the direct path (every
  *                        fragment resolved with a 64-bit atomic min in HBM).
  *   AR_OPT_OVERLAP       1 (default): consecutive ar_render_async frames of the tiled path run on three
  *                        streams of the context in rotation, each with its own set of buffers, so that up to
  *                        three frames share the GPU (no events between them); 0: one stream, frames strictly
  *                        one after the other.  ar_render (blocking) never overlaps.
  *   AR_OPT_POOL_RECORDS  capacity of the tiled path's (sub-triangle, bin) entry pool in entries;
- *                        0 (default) sizes it as 2 x triangles + 65536. */
+ *                        0 (default) sizes it as 2 x triangles + 65536.
+ *   AR_OPT_TILE_ROWS     height of the tiled path's tiles: 0 (default) picks 32 rows, or 16 or 8 when the frame
+ *                        (a strip, a small grid) would otherwise have fewer than 512 tiles; 8, 16, 32 fix it. */
 #define AR_OPT_PATH 1
 #define AR_OPT_POOL_RECORDS 2
 #define AR_OPT_OVERLAP 3
+#define AR_OPT_TILE_ROWS 4
 int ar_set_option(ar_ctx *ctx, int option, long long value);
 
 #ifdef __cplusplus

@@ -116,6 +116,7 @@ def main():
             continue
         c = make_case(rng)
         R.set_option("path", c["path"]); R.set_option("pool_records", c["pool"]); R.set_option("overlap", min(c["overlap"], 1))
+        R.set_option("tile_rows", (0, 8, 16, 32, 0)[n % 5])      # the tile height: chosen by the library, or each fixed one
         if c["indexed"] is not None:
             R.set_mesh_indexed(*c["indexed"])
         else:

@@ -1,13 +1,18 @@
 """What one rank of an N-GPU run does, measured on one GPU: frames/s when only the rows of rank r of N are
-rendered (C3 workload, frames overlapped, outputs resident; no gather).  The slowest rank bounds the N-GPU rate."""
+rendered (frames overlapped, outputs resident; no gather).  The slowest rank bounds the N-GPU rate.
+AR_CONFIG = C3 (default: 1M triangles, 1920x1080), C4 (the same mesh at 3840x2160) or C5 (10M triangles, four
+point lights, 1920x1080)."""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ar = importlib.import_module("ascii-renderer_amd")
 mg = importlib.import_module("ascii-renderer_amd.multigpu")
 if os.environ.get("AR_LIB"):
     ar.binding.LIB_PATH = os.environ["AR_LIB"]
-cols, rows = 1920, 1080
-sc = ar.scenes.random_scene(1_000_000, cols, rows)
+config = os.environ.get("AR_CONFIG", "C3")
+cols, rows = (3840, 2160) if config == "C4" else (1920, 1080)
+sc = (ar.scenes.random_scene(10_000_000, cols, rows, seed=0xA5C12, point_lights=True) if config == "C5"
+      else ar.scenes.random_scene(1_000_000, cols, rows))
+print("config %s: %d triangles, %dx%d" % (config, sc["idx"].size // 3, cols, rows), flush=True)
 R = ar.Renderer(0)
 ar.scenes.upload(R, sc)
 for world in (1, 2, 4, 8):
@@ -19,7 +24,7 @@ for world in (1, 2, 4, 8):
         R.sync()
         best = 0.0
         for rep in range(3):
-            t0 = time.perf_counter(); n = 300
+            t0 = time.perf_counter(); n = 100 if config == "C5" else 300
             for _ in range(n): R.render_async(cols, rows)
             R.sync()
             best = max(best, n / (time.perf_counter() - t0))
