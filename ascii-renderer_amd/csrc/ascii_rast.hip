@@ -303,22 +303,34 @@ int ar_sync(ar_ctx *ctx) {
     return sync_streams(ctx);
 }
 
+namespace {
+
+// Copies the planes of the most recent frame that are wanted to host memory, on the stream that frame ran on (so the
+// copies queue behind its kernels without a wait of their own), then waits once.
+int read_outputs(ar_ctx *ctx, hipStream_t s, uint8_t *rgba, float *depth, uint8_t *ascii, uint32_t *ids) {
+    const size_t n = size_t(ctx->cols) * ctx->rows;
+    const int o = ctx->last_oset;
+    if (ids && !ctx->d_ids[o]) return fail(ctx, AR_E_STATE, "ar_read: ids wanted but ar_set_id_output was not on for the last frame");
+    hipError_t e = hipSuccess;
+    if (rgba && e == hipSuccess) e = hipMemcpyAsync(rgba, ctx->d_rgba[o], n * 4, hipMemcpyDeviceToHost, s);
+    if (depth && e == hipSuccess) e = hipMemcpyAsync(depth, ctx->d_depth[o], n * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (ascii && e == hipSuccess) e = hipMemcpyAsync(ascii, ctx->d_ascii[o], n, hipMemcpyDeviceToHost, s);
+    if (ids && e == hipSuccess) e = hipMemcpyAsync(ids, ctx->d_ids[o], n * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    const hipError_t done = hipStreamSynchronize(s);  // also after a failure: no copy into the caller's memory may outlive the call
+    if (e != hipSuccess) return fail(ctx, AR_E_HIP, "device-to-host copy failed: %s", hipGetErrorString(e));
+    if (done != hipSuccess) return fail(ctx, AR_E_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(done));
+    return 0;
+}
+
+}  // namespace
+
 int ar_read(ar_ctx *ctx, uint8_t *rgba, float *depth, uint8_t *ascii, uint32_t *ids) {
     if (!ctx) return AR_E_ARG;
     if (!ctx->rendered) return fail(ctx, AR_E_STATE, "ar_read: no frame has been rendered at this grid size");
     AR_HIP(ctx, hipSetDevice(ctx->device));
     int rc = sync_streams(ctx);
     if (rc) return rc;
-    const size_t n = size_t(ctx->cols) * ctx->rows;
-    const int o = ctx->last_oset;
-    if (rgba) AR_HIP(ctx, hipMemcpy(rgba, ctx->d_rgba[o], n * 4, hipMemcpyDeviceToHost));
-    if (depth) AR_HIP(ctx, hipMemcpy(depth, ctx->d_depth[o], n * sizeof(float), hipMemcpyDeviceToHost));
-    if (ascii) AR_HIP(ctx, hipMemcpy(ascii, ctx->d_ascii[o], n, hipMemcpyDeviceToHost));
-    if (ids) {
-        if (!ctx->d_ids[o]) return fail(ctx, AR_E_STATE, "ar_read: ids wanted but ar_set_id_output was not on for the last frame");
-        AR_HIP(ctx, hipMemcpy(ids, ctx->d_ids[o], n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    }
-    return 0;
+    return read_outputs(ctx, ctx->stream, rgba, depth, ascii, ids);
 }
 
 int ar_render(ar_ctx *ctx, int cols, int rows, uint8_t *rgba, float *depth, uint8_t *ascii) {
@@ -326,7 +338,8 @@ int ar_render(ar_ctx *ctx, int cols, int rows, uint8_t *rgba, float *depth, uint
     int rc = enqueue_frame(ctx, cols, rows, false);
     if (rc) return rc;
     if (ctx->n_tris == 0 || !ctx->rendered) return ar_sync(ctx);  // no geometry: outputs stay untouched (raster.js:274)
-    return ar_read(ctx, rgba, depth, ascii, nullptr);
+    // a blocking frame runs on ctx->stream alone (enqueue_frame has waited for any overlapped frames before it)
+    return read_outputs(ctx, ctx->stream, rgba, depth, ascii, nullptr);
 }
 
 void *ar_device_buffer(ar_ctx *ctx, int which) {

@@ -235,12 +235,155 @@ __global__ __launch_bounds__(256) void k_ascii_plane(FrameParams fp, const uint8
     }
 }
 
+// Modal smoothing over a plane of ramp indices for short ramps (at most 10 characters) and radius 1 or 2: the same
+// result as k_ascii_plane from counting instead of voting.  A lane owns four consecutive cells of a row.  It builds,
+// for each of the 4 + 2R columns its windows touch, a histogram of the column's 2R + 1 values - ten 6-bit counters
+// in one 64-bit word - so that a cell's window is a sum of 2R + 1 column words minus the cell itself, and the next
+// cell's window is that sum plus one column minus another.  What the shader's two passes decide (the Boyer-Moore
+// candidate, then its true vote count against the threshold) follows from the counts in all but one case:
+//   no value reaches the threshold                       -> whatever the candidate is, it is not voted in: the cell stays;
+//   some value holds a strict majority of the neighbours -> it is the candidate (that is what Boyer-Moore guarantees),
+//                                                           and it has the votes whenever the threshold is at most
+//                                                           its count - it replaces the cell;
+//   values reach the threshold, none holds a majority    -> the candidate depends on the order of the neighbours: those
+//                                                           cells are queued and a second step runs the shader's two
+//                                                           passes on them as written, from the staged tile.
+// The codes go through LDS so that the queued cells' bytes are in place before a lane stores its four.
+template <int R>
+__global__ __launch_bounds__(256) void k_ascii_counts(FrameParams fp, const uint8_t *__restrict__ src, uint8_t *__restrict__ ascii) {
+    constexpr int TWD = 34, TH = 8 + 2 * R;  // as k_ascii_plane: dwords per tile row (4 bytes of halo either side), tile rows
+    constexpr int N = (2 * R + 1) * (2 * R + 1) - 1, NC = 4 + 2 * R;
+    constexpr unsigned long long kOnes = 0x0041041041041041ull;  // bit 0 of each of the ten 6-bit fields
+    __shared__ uint32_t tile[TWD * TH];
+    __shared__ uint8_t ramp[AR_MAX_RAMP];
+    __shared__ uint32_t codes[256];   // the workgroup's 128 x 8 output codes, a lane's four in one word
+    __shared__ uint16_t queue[1024];  // cells (row * 128 + column within the workgroup's block) left to the second step
+    __shared__ uint32_t n_queue;
+    const int x0 = int(blockIdx.x) * 128, y0 = fp.row0 + int(blockIdx.y) * 8;
+    ramp[threadIdx.x] = fp.ramp[threadIdx.x];
+    if (threadIdx.x == 0) n_queue = 0;
+    const bool cols4 = (fp.cols & 3) == 0;
+    for (int k = int(threadIdx.x); k < TWD * TH; k += 256) {
+        const int ty = k / TWD, td = k - ty * TWD;
+        const int gy = min(max(y0 + ty - R, 0), fp.rows - 1);
+        const int gx = x0 - 4 + 4 * td;  // column of the dword's first byte
+        const uint8_t *row = src + size_t(gy) * fp.cols;
+        uint32_t v;
+        if (cols4 && gx >= 0 && gx + 3 < fp.cols) {
+            v = *reinterpret_cast<const uint32_t *>(row + gx);
+        } else {
+            v = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) v |= uint32_t(row[min(max(gx + q, 0), fp.cols - 1)]) << (8 * q);
+        }
+        tile[k] = v;
+    }
+    __syncthreads();
+    const int lx = int(threadIdx.x & 31u), ly = int(threadIdx.x >> 5);
+    const int x = x0 + 4 * lx, y = y0 + ly;
+    const bool live = x < fp.cols && y < fp.row1;
+    // field f of a count word holds how many of the neighbours have ramp index f.  Adding 32 - t to every field sets
+    // its top bit exactly when the count is at least t (counts are at most N <= 24, so no field overflows).
+    const int thresh = fp.mode_thresh;  // (the launcher sends only 1 <= thresh <= 32 here)
+    const unsigned long long kTop = kOnes << 5;
+    const unsigned long long k_thresh = kOnes * (unsigned long long)(32 - thresh);
+    const unsigned long long k_major = kOnes * (unsigned long long)(32 - (N / 2 + 1));
+    if (live) {
+        unsigned long long col[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) col[c] = 0ull;
+        uint32_t centre = 0;
+#pragma unroll
+        for (int dy = -R; dy <= R; dy++) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const uint32_t w = tile[(ly + R + dy) * TWD + lx + q];
+                if (dy == 0 && q == 1) centre = w;
+                const uint32_t w6 = (w << 2) + (w << 1);  // six times every byte (indices are below 10: no carries)
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int p = 4 * q + b;  // byte p of a window row is column x - 4 + p
+                    if (p < 4 - R || p > 7 + R) continue;
+                    col[p - (4 - R)] += 1ull << ((w6 >> (8 * b)) & 255u);
+                }
+            }
+        }
+        unsigned long long win = 0ull;
+#pragma unroll
+        for (int c = 0; c <= 2 * R; c++) win += col[c];
+        uint32_t out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int base = int((centre >> (8 * j)) & 255u);
+            const unsigned long long cnt = win - (1ull << (6 * base));  // the neighbours: the window without the cell itself
+            if (j < 3) win += col[j + 2 * R + 1] - col[j];
+            int fin = base;
+            const unsigned long long reach = (cnt + k_thresh) & kTop;
+            if (reach != 0ull) {
+                const unsigned long long major = (cnt + k_major) & kTop;
+                const unsigned long long pick = thresh > N / 2 ? reach : major;
+                if (pick != 0ull) {
+                    fin = ((__ffsll((long long)pick) - 1) * 43) >> 8;  // top bit 6 f + 5 of the only such field -> f
+                } else {
+                    queue[atomicAdd(&n_queue, 1u)] = uint16_t(ly * 128 + 4 * lx + j);
+                }
+            }
+            out |= uint32_t(fin < fp.ramp_len ? ramp[fin] : uint8_t(32)) << (8 * j);
+        }
+        codes[threadIdx.x] = out;
+    }
+    __syncthreads();
+    // second step: the shader's two passes, as written, for the queued cells
+    const uint32_t nq = n_queue;
+    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(tile);
+    for (uint32_t k = threadIdx.x; k < nq; k += 256) {
+        const int cell = int(queue[k]), cy = cell >> 7, cx = cell & 127;
+        int nb[N];
+        {
+            int q = 0;
+#pragma unroll
+            for (int dy = -R; dy <= R; dy++)
+#pragma unroll
+                for (int dx = -R; dx <= R; dx++)
+                    if (dx != 0 || dy != 0) nb[q++] = bytes[(cy + R + dy) * (TWD * 4) + 4 + cx + dx];
+        }
+        const int base = bytes[(cy + R) * (TWD * 4) + 4 + cx];
+        int cand = -1, count = 0, votes = 0;
+#pragma unroll
+        for (int q = 0; q < N; q++) {
+            if (count == 0) { cand = nb[q]; count = 1; }
+            else if (nb[q] == cand) count += 1;
+            else count -= 1;
+        }
+#pragma unroll
+        for (int q = 0; q < N; q++) votes += nb[q] == cand ? 1 : 0;
+        const int fin = (votes >= thresh && cand != base) ? cand : base;
+        reinterpret_cast<uint8_t *>(codes)[cell] = (fin >= 0 && fin < fp.ramp_len) ? ramp[fin] : uint8_t(32);
+    }
+    __syncthreads();
+    if (!live) return;
+    const uint32_t out = codes[threadIdx.x];
+    uint8_t *dst = ascii + size_t(y) * fp.cols + x;
+    if (cols4) {
+        *reinterpret_cast<uint32_t *>(dst) = out;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (x + j < fp.cols) dst[j] = uint8_t(out >> (8 * j));
+    }
+}
+
 template <bool FROM_RGBA>
 void launch_ascii(const FrameParams &fp, const void *src, uint8_t *ascii, hipStream_t stream) {
     const int radius = fp.mode_radius < 1 ? 1 : (fp.mode_radius > 3 ? 3 : fp.mode_radius);  // shader clamps to 1..3
     if constexpr (!FROM_RGBA) {
         const dim3 grid((fp.cols + 127) / 128, (fp.row1 - fp.row0 + 7) / 8);
         const uint8_t *plane = static_cast<const uint8_t *>(src);
+        if (fp.ramp_len <= 10 && radius <= 2 && fp.mode_thresh >= 1 && fp.mode_thresh <= 32) {  // the counting kernel's domain
+            if (radius == 1) k_ascii_counts<1><<<grid, 256, 0, stream>>>(fp, plane, ascii);
+            else k_ascii_counts<2><<<grid, 256, 0, stream>>>(fp, plane, ascii);
+            return;
+        }
         if (radius == 1) k_ascii_plane<1><<<grid, 256, 0, stream>>>(fp, plane, ascii);
         else if (radius == 2) k_ascii_plane<2><<<grid, 256, 0, stream>>>(fp, plane, ascii);
         else k_ascii_plane<3><<<grid, 256, 0, stream>>>(fp, plane, ascii);

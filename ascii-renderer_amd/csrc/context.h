@@ -392,7 +392,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
             auto kernel = fp.tshift == 5 ? (textured ? k_tile<true, 5> : k_tile<false, 5>)
                           : fp.tshift == 4 ? (textured ? k_tile<true, 4> : k_tile<false, 4>)
                                            : (textured ? k_tile<true, 3> : k_tile<false, 3>);
-            kernel<<<grid, 256, 0, fs>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_triuv,
+            kernel<<<grid, kTileThreads, 0, fs>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_triuv,
                                          ctx->d_atlas, ctx->d_tri, ctx->d_tri_t, ctx->d_entries[set], ctx->pool_cap, ctx->d_state,
                                          ctx->d_vis[set], ctx->d_rgba[oset], ctx->d_depth[oset], ascii_out, ctx->d_ridx[set],
                                          ctx->d_ids[oset]);

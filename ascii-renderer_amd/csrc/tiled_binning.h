@@ -55,6 +55,7 @@ constexpr int kTileSmallCells = 64;   // cell-range area (inside the tile) one l
 constexpr int kTileListMax = 2048;    // ids staged in LDS between the filter and the raster step
 constexpr int kEntryMaskShift = 28;   // a bin entry is (2*triangle + sub) | (mask of the bin's 2x2 tiles) << 28
 constexpr uint32_t kEntryLocMask = (1u << kEntryMaskShift) - 1u;
+constexpr int kTileThreads = 256;     // k_tile workgroup size
 constexpr int kFilterBatch = 4;       // bin entries a k_tile lane loads per filter step
 constexpr uint32_t kFlagFlat = 2u;    // the triangle's three vertices carry identical normal and colour
 constexpr uint32_t kFlagTextured = 4u;  // the triangle samples the atlas (set from its texel-coordinate row)

@@ -246,7 +246,7 @@ __device__ __forceinline__ void raster_range(const FrameParams &fp, const Edges 
 
 // TEX: the frame samples an atlas (texel coordinates and atlas are only read then).  SH: log2 of the tile height.
 template <bool TEX, int SH>
-__global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__restrict__ vbo,
+__global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const float *__restrict__ vbo,
                                               const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
                                               const uint4 *__restrict__ triuv, const uint32_t *__restrict__ atlas,
                                               const TriStatic *__restrict__ tri, const TriStatic *__restrict__ tri_t,
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
     const uint32_t bit = 1u << sub;
     const int jlo = fp.rows - fp.yb, jhi = fp.rows - 1 - fp.ya;  // window rows of the frame's strip, as in k_setup
     const BinState &st = state[fp.set];
-    for (int c = int(tid); c < kTileCells; c += 256) keys[c] = kBackgroundKey;
+    for (int c = int(tid); c < kTileCells; c += kTileThreads) keys[c] = kBackgroundKey;
     if (tid == 0) { n_list = 0; n_big = 0; n_cov = 0; }
     const uint32_t e_begin = st.start[bin];
     const uint32_t e_total = st.total[bin];
@@ -288,11 +288,11 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
     // filter the bin's entries by this tile's mask bit into the LDS list; whenever the list could
     // overflow on the next step (or at the end) rasterise what it holds
     // (kFilterBatch entries per lane and step, all loads in flight together: the step is one memory latency)
-    for (uint32_t eb = e_begin;; eb += 256 * kFilterBatch) {
+    for (uint32_t eb = e_begin;; eb += kTileThreads * kFilterBatch) {
         uint32_t ent[kFilterBatch];
 #pragma unroll
         for (int q = 0; q < kFilterBatch; q++) {
-            const uint32_t e = eb + uint32_t(q) * 256u + tid;
+            const uint32_t e = eb + uint32_t(q) * uint32_t(kTileThreads) + tid;
             ent[q] = e < e_end ? entries[e] : 0u;  // mask 0 never matches
         }
 #pragma unroll
@@ -304,16 +304,16 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
         // raster block goes straight to the next step's appends): the flush decision below has to be the same
         // in all of them, because the block contains barriers
         __syncthreads();
-        const bool last = eb + 256 * kFilterBatch >= e_end;
-        if (nl + 256 * kFilterBatch > uint32_t(kTileListMax) || last) {
+        const bool last = eb + kTileThreads * kFilterBatch >= e_end;
+        if (nl + kTileThreads * kFilterBatch > uint32_t(kTileListMax) || last) {
             // sub-triangles with a small cell range inside the tile: one lane each; others -> sweep list
             // (a lane's next triangle record is fetched while it works on the current one).
             // A short list leaves most lanes without a triangle, and the few that have one walk their rows one
             // after the other: then 2, 4, 8 or 16 neighbouring lanes share a triangle - each redoes its setup (for
             // nothing: the wavefront executes those instructions anyway) and takes an equal share of its rows.
             int gshift = 0;
-            while (gshift < 4 && (nl << (gshift + 1)) <= 256u) gshift++;
-            const uint32_t per_round = 256u >> gshift, first = tid >> gshift;
+            while (gshift < 4 && (nl << (gshift + 1)) <= uint32_t(kTileThreads)) gshift++;
+            const uint32_t per_round = uint32_t(kTileThreads) >> gshift, first = tid >> gshift;
             const int part = int(tid & ((1u << gshift) - 1u));
             TriStatic ahead;
             if (first < nl) ahead = tri[list[first] >> 1];
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
                 const uint32_t ns = min(uint32_t(kTileStage), nb - b0);
                 if (tid < ns) stage[tid] = tri[big[b0 + tid] >> 1];
                 __syncthreads();
-                for (uint32_t q = tid >> 6; q < ns; q += 4) {
+                for (uint32_t q = tid >> 6; q < ns; q += kTileThreads / 64) {
                     const uint32_t id = big[b0 + q];
                     const uint32_t key_id = 2u * (stage[q].flags >> kFlagBits) + (id & 1u);
                     float p[9];
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
 
     // sub-triangles k_fill could not store were resolved through the global key buffer
     if (st.overflow != 0) {
-        for (int c = int(tid); c < kTileCells; c += 256) {
+        for (int c = int(tid); c < kTileCells; c += kTileThreads) {
             const int rr = tr0 + (c >> 6), i = tx0 + (c & 63);
             if (i > tx1 || rr > tr1) continue;
             const size_t cell = size_t(rr) * fp.cols + i;
@@ -406,11 +406,11 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
     }
 
     // compact the covered cells so that shading runs on full wavefronts
-    for (int c = int(tid); c < kTileCells; c += 256)
+    for (int c = int(tid); c < kTileCells; c += kTileThreads)
         if (keys[c] != kBackgroundKey) covered[atomicAdd(&n_cov, 1u)] = uint16_t(c);
     __syncthreads();
     const uint32_t nc = n_cov;
-    for (uint32_t k = tid; k < nc; k += 256) {
+    for (uint32_t k = tid; k < nc; k += kTileThreads) {
         const int c = int(covered[k]);
         const int rr = tr0 + (c >> 6), i = tx0 + (c & 63);
         const uint32_t low = uint32_t(keys[c]);  // the key's low word is the winner: (2*triangle + sub) << 1 | clipped
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
     // the tile's rows.  Usual case: a lane writes four consecutive cells of a row, one 16-byte store each for colour
     // and depth and one dword of ramp indices (rows and the tile's columns start at multiples of four cells)
     if ((fp.cols & 3) == 0 && fp.mode_on && !fp.want_ids) {
-        for (int q = int(tid); q < kTileCells / 4; q += 256) {
+        for (int q = int(tid); q < kTileCells / 4; q += kTileThreads) {
             const int row = q >> 4, x = (q & 15) * 4;
             const int rr = tr0 + row, i = tx0 + x;
             if (i > tx1 || rr > tr1) continue;  // (a group of four lies inside or outside the grid as a whole)
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void k_tile(FrameParams fp, const float *__res
         }
         return;
     }
-    for (int c = int(tid); c < kTileCells; c += 256) {
+    for (int c = int(tid); c < kTileCells; c += kTileThreads) {
         const int rr = tr0 + (c >> 6), i = tx0 + (c & 63);
         if (i > tx1 || rr > tr1) continue;
         const size_t cell = size_t(rr) * fp.cols + i;

@@ -22,6 +22,16 @@ for name, sc in cases:
     t0 = time.perf_counter()
     for _ in range(n): R.render(cols, rows)
     blocking = n / (time.perf_counter() - t0)
+    # the backend's render(time, framebuffer, state): a blocking frame into the caller's RGBA framebuffer (page-locked, from
+    # ar_host_alloc), and the same with the ASCII plane as well
+    import numpy as np
+    fb, asc = R.host_array((rows, cols, 4), np.uint8), R.host_array((rows, cols), np.uint8)
+    drop = {}
+    for label, kw in (("rgba", {"rgba": fb}), ("rgba+ascii", {"rgba": fb, "ascii": asc})):
+        for _ in range(50): R.render_into(cols, rows, **kw)
+        t0 = time.perf_counter()
+        for _ in range(n): R.render_into(cols, rows, **kw)
+        drop[label] = n / (time.perf_counter() - t0)
     for _ in range(50): R.render_async(cols, rows)
     R.sync()
     t0 = time.perf_counter()
@@ -32,4 +42,5 @@ for name, sc in cases:
     for _ in range(100): R.render_async(cols, rows)
     st = R.kernel_stats(); R.set_profiling(False); R.set_option("overlap", 1)
     us = {k: round(1e3 * ms / c, 1) for k, (c, ms) in st.items() if c}
-    print("%-34s blocking+readback %7.0f frames/s (%.1f us)   resident %7.0f frames/s   kernels us %s" % (name, blocking, 1e6 / blocking, resident, us), flush=True)
+    print("%-34s blocking, all planes into new arrays %7.0f frames/s (%.1f us)   into a page-locked framebuffer: rgba %7.0f, rgba + ascii %7.0f   resident %7.0f frames/s   kernels us %s"
+          % (name, blocking, 1e6 / blocking, drop["rgba"], drop["rgba+ascii"], resident, us), flush=True)

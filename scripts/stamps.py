@@ -12,6 +12,7 @@ ar.scenes.upload(R, sc)
 for _ in range(5): R.render_async(sc["cols"], sc["rows"])
 R.sync()
 L = ar.load_library()
+R.set_option("tile_rows", 32)
 ntx, nty = (sc["cols"] + 63) // 64, (sc["rows"] + 31) // 32
 n_wg = ((((ntx + 1) // 2) * ((nty + 1) // 2) + 7) // 8 * 8) * 4        # k_tile's grid: bins rounded up to 8, four tiles each
 n = n_wg * 8
@@ -28,7 +29,27 @@ for k, nm in enumerate(names):
 tot = (st[:, 6] - st[:, 0]) / 100.0
 print("tile total   mean %6.2f us p95 %6.2f max %6.2f;  start spread %.2f us; kernel span %.2f us" % (
     tot.mean(), np.percentile(tot, 95), tot.max(), (st[:, 0].max() - t0) / 100.0, (st[:, 6].max() - t0) / 100.0))
+hw = st[:, 7] & 0xFFFFFFFF
+xcc = (st[:, 7] >> 32) & 15
+st[:, 7] = st[:, 7] >> 40
 print("records per tile mean %.0f max %d" % (st[:, 7].mean(), st[:, 7].max()))
+# where the tiles ran: XCD, and the compute unit within it (HW_ID: cu_id bits 11:8, sh_id bit 12, se_id bits 15:13)
+cu = (hw >> 8) & 0xFF
+for x in range(8):
+    m = xcc == x
+    if m.any():
+        print("xcd %d: %4d tiles, tile total mean %.2f max %.2f, end of last tile %.2f us, distinct CUs %d" % (
+            x, m.sum(), tot[m].mean(), tot[m].max(), (st[m, 6].max() - t0) / 100.0, len(set(cu[m].tolist()))))
+key = xcc * 256 + cu
+per_cu = {}
+for k, e, t in zip(key.tolist(), ((st[:, 6] - t0) / 100.0).tolist(), tot.tolist()):
+    per_cu.setdefault(k, []).append((e, t))
+cnt = np.array([len(v) for v in per_cu.values()])
+end = np.array([max(e for e, _ in v) for v in per_cu.values()])
+print("CUs used %d; tiles per CU min %d mean %.2f max %d; CU end time mean %.2f p95 %.2f max %.2f" % (
+    len(per_cu), cnt.min(), cnt.mean(), cnt.max(), end.mean(), np.percentile(end, 95), end.max()))
+for c in sorted(set(cnt.tolist())):
+    print("  CUs with %d tiles: %3d, end time mean %.2f max %.2f" % (c, (cnt == c).sum(), end[cnt == c].mean(), end[cnt == c].max()))
 rs = (st[:, 2] - st[:, 1]) / 100.0
 nrec = st[:, 7]
 for lo, hi in ((0, 448), (448, 480), (480, 512), (512, 544), (544, 1000)):

@@ -8,7 +8,9 @@ if os.environ.get("AR_LIB"):
 tris = int(os.environ.get("AR_TRIS", "1000000")); cols = int(os.environ.get("AR_COLS", "1920")); rows = int(os.environ.get("AR_ROWS", "1080"))
 sc = ar.scenes.random_scene(tris, cols, rows, point_lights=bool(os.environ.get("AR_PL")))
 R = ar.Renderer(0)
-ar.scenes.upload(R, sc)
+ar.scenes.upload(R, sc, mode_on=not os.environ.get("AR_NO_SMOOTHING"))
+if os.environ.get("AR_TILE_ROWS"):
+    R.set_option("tile_rows", int(os.environ["AR_TILE_ROWS"]))
 res = {}
 for ov in (1, 0):
     R.set_option("overlap", ov)
