@@ -401,6 +401,22 @@ napi_value js_quantize(napi_env env, napi_callback_info info) {
     return nullptr;
 }
 
+// quantizeStatic(handle, rgba, cols, rows, outAscii): ar_quantize_static (no device allocation on the way)
+napi_value js_quantize_static(napi_env env, napi_callback_info info) {
+    napi_value argv[5];
+    if (!get_args(env, info, 5, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    void *rgba, *ascii;
+    size_t nr, na;
+    const int cols = get_i32(env, argv[2]), rows = get_i32(env, argv[3]);
+    if (!get_typed(env, argv[1], napi_uint8_array, &rgba, &nr, false) || !get_typed(env, argv[4], napi_uint8_array, &ascii, &na, false)) return nullptr;
+    const size_t n = size_t(cols > 0 ? cols : 0) * size_t(rows > 0 ? rows : 0);
+    if (nr != n * 4 || na != n) { napi_throw_range_error(env, nullptr, "quantizeStatic: array sizes do not match cols*rows"); return nullptr; }
+    if (ar_quantize_static(ctx, static_cast<const uint8_t *>(rgba), cols, rows, static_cast<uint8_t *>(ascii))) return throw_ar(env, ctx, "ar_quantize_static");
+    return nullptr;
+}
+
 // quantizeColors(handle, rgba, cols, rows, steps, grayscale, outUint32Array)
 napi_value js_quantize_colors(napi_env env, napi_callback_info info) {
     napi_value argv[7];
@@ -510,6 +526,7 @@ napi_value init(napi_env env, napi_value exports) {
         {"rtSetScene", nullptr, js_rt_set_scene, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"rtRender", nullptr, js_rt_render, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"quantize", nullptr, js_quantize, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"quantizeStatic", nullptr, js_quantize_static, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"frameCounters", nullptr, js_frame_counters, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"allocHost", nullptr, js_alloc_host, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"quantizeColors", nullptr, js_quantize_colors, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

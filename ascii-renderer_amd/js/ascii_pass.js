@@ -34,6 +34,9 @@ export class AsciiPass {
     this.alphaGamma = Number.isFinite(opts.alphaGamma) ? opts.alphaGamma : 1.20;
     this.alphaBias = Number.isFinite(opts.alphaBias) ? opts.alphaBias : 0.045;
     this.transparentBackground = opts.transparentBackground !== undefined ? !!opts.transparentBackground : true;
+    // not in the reference: draw() through the library's fixed staging array (ar_quantize_static), for hosts that
+    // must not cause device allocations once set up; grids beyond 1920 x 1080 cells then throw
+    this.noAlloc = !!opts.noAlloc;
     // modal smoothing controls come from config at construction (ascii_pass.js:149-152)
     this.modeFilter = !!config.ASCII_MODE_FILTER;
     const k = Math.max(3, (config.ASCII_MODE_KERNEL | 0) || 3);
@@ -131,7 +134,8 @@ export class AsciiPass {
     const N = native();
     const r = Math.max(1, Math.min(3, this.modeRadius | 0));   // MAX_MODE_RADIUS = 3 (ascii_pass.js:296-297)
     N.setAscii(this._h, rampBytes(this.ramp), this.modeFilter, r, this.modeThresh | 0);
-    N.quantize(this._h, this._src, this.cols, this.rows, this.codes);
+    if (this.noAlloc) N.quantizeStatic(this._h, this._src, this.cols, this.rows, this.codes);
+    else N.quantize(this._h, this._src, this.cols, this.rows, this.codes);
     return this.codes;
   }
 

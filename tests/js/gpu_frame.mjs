@@ -64,6 +64,16 @@ const dump = (name, ta) => fs.writeFileSync(path.join(outDir, name), Buffer.from
   for (let i = 0; i < text.length; i++) { const p = (5 * 640 + 10 + i) * 4; ui[p] = ui[p + 1] = ui[p + 2] = 0; ui[p + 3] = text.charCodeAt(i) & 0xFF; }
   const pass = new AsciiPass();
   const codes = pass.drawFromBuffer(ui, 640, 360);
+  {   // the same grid through the entry point that allocates nothing
+    const fixed = new AsciiPass({ noAlloc: true });
+    const same = fixed.drawFromBuffer(ui, 640, 360);
+    if (Buffer.compare(Buffer.from(same.buffer, same.byteOffset, same.byteLength), Buffer.from(codes.buffer, codes.byteOffset, codes.byteLength)) !== 0)
+      throw new Error('AsciiPass({noAlloc}) differs from AsciiPass');
+    let refused = false;
+    try { fixed.drawFromBuffer(new Uint8Array(1921 * 1080 * 4), 1921, 1080); } catch (e) { refused = /exceed/.test(String(e.message)); }
+    if (!refused) throw new Error('a grid beyond the static staging array must be refused');
+    fixed.dispose();
+  }
   const colors = pass.colorsFromBuffer(ui, 640, 360);
   if (!(colors instanceof Uint32Array) || colors.length !== 640 * 360) throw new Error('colorsFromBuffer shape');
   dump('ico_ui.colors', colors);
