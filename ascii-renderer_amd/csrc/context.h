@@ -46,6 +46,7 @@ struct ar_ctx {
     int path = 0;                    // 0: tiled when the grid allows it, 1: always the direct path
     uint32_t pool_cap_option = 0;    // 0: sized from the triangle count
     int tile_shift_option = 0;       // 0: tile height chosen per frame; 3, 4, 5: fixed at 8, 16, 32 rows
+    bool no_classes = false;         // AR_OPT_WORK_CLASSES 0: tile lists stay in entry order
     float *d_tripos = nullptr;       // 9 planes x tripos_stride floats: triangle positions
     size_t tripos_stride = 0;
     float *d_triattr = nullptr;      // n_tris x 24 floats: the three vertices' normals and colours
@@ -318,6 +319,10 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
         fp.n_groups = (fp.n_tris + chunk - 1) / chunk;
         fp.frame = ctx->frame;
         fp.set = set;
+        fp.id_bits = 1;
+        while (fp.id_bits < kEntryMaskShift && (2ull * fp.n_tris - 1) >> fp.id_bits) fp.id_bits++;
+        fp.cls_bits = std::min(kEntryMaskShift - fp.id_bits, kMaxClassBits);
+        if (ctx->no_classes) fp.cls_bits = 0;
         const uint32_t want_cap = ctx->pool_cap_option ? ctx->pool_cap_option : 2u * fp.n_tris + 65536u;
         if (!ctx->d_entries[0] || ctx->pool_cap != want_cap) {
             rc = sync_streams(ctx);

@@ -35,6 +35,8 @@ struct FrameParams {
     int nbx, nby;    // bin grid
     int bshift;      // a bin is (1 << bshift)^2 tiles: 0 while the tiles fit the bin table, else 1
     int tshift;      // log2 of the tile height in rows (5, 4 or 3)
+    int id_bits;     // bits of a bin entry that hold 2*slot + sub (enough for the mesh) ...
+    int cls_bits;    // ... and, above them, so many bits of work class (0..6; what is left below the tile mask)
     uint32_t chunk, n_groups;  // triangles per k_setup workgroup, number of those workgroups
     uint32_t frame;  // frame counter
     int set;         // buffer set of this frame (frame % kSets): binning state block, survivor slots, ...

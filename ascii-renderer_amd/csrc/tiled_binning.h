@@ -53,7 +53,8 @@ constexpr int kTileBigMax = 512;      // per-tile list of triangles swept cooper
 constexpr int kTileStage = 64;        // of which so many are staged in LDS at a time (64 B each, in the cell list's 4 KB)
 constexpr int kTileSmallCells = 64;   // cell-range area (inside the tile) one lane scans itself
 constexpr int kTileListMax = 2048;    // ids staged in LDS between the filter and the raster step
-constexpr int kEntryMaskShift = 28;   // a bin entry is (2*triangle + sub) | (mask of the bin's 2x2 tiles) << 28
+constexpr int kEntryMaskShift = 28;   // a bin entry is (2*slot + sub) | work class << id_bits | (mask of the bin's 2x2 tiles) << 28
+constexpr int kMaxClassBits = 6;      // work classes of a bin entry: up to 64 (fewer when the mesh needs the bits for its slots)
 constexpr uint32_t kEntryLocMask = (1u << kEntryMaskShift) - 1u;
 constexpr int kTileThreads = 256;     // k_tile workgroup size
 constexpr int kFilterBatch = 4;       // bin entries a k_tile lane loads per filter step
@@ -616,6 +617,12 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Tr
         const int tx0 = i0 >> 6, tx1 = i1 >> 6, ty0 = r0 >> fp.tshift, ty1 = r1 >> fp.tshift;
         int bx0, bx1, by0, by1;
         bin_range(fp, i0, i1, j0, j1, bx0, bx1, by0, by1);
+        // work class: rows of the cell range above its width, each clamped to its share of the class bits.  A lane of
+        // k_tile walks a triangle's rows and then its candidate cells, and a wavefront takes as long as its slowest
+        // lane: k_tile orders every tile's list by this class so that a wavefront's triangles are of one kind.  The
+        // class steers the order of the work only, never a result.
+        const int hb = min(fp.cls_bits, 3), wb = fp.cls_bits - hb;
+        const uint32_t cls = uint32_t(((min(j1 - j0 + 1, 1 << hb) - 1) << wb) | (min(i1 - i0 + 1, 1 << wb) - 1)) << fp.id_bits;
         bool direct = false;
         for (int by = by0; by <= by1; by++)
             for (int bx = bx0; bx <= bx1; bx++) {
@@ -628,7 +635,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Tr
                 const uint32_t rowbits = ((1u << (ax1 + 1)) - 1u) & ~((1u << ax0) - 1u);
                 uint32_t m = 0;
                 for (int ay = ay0; ay <= ay1; ay++) m |= rowbits << (side * ay);
-                entries[size_t(base[b]) + atomicAdd(&cnt[b], 1u)] = id | (m << kEntryMaskShift);
+                entries[size_t(base[b]) + atomicAdd(&cnt[b], 1u)] = id | cls | (m << kEntryMaskShift);
             }
         if (direct) {  // a bin it touches has no room: resolve through the global key buffer
             const TriStatic ts = tri[id >> 1];

@@ -169,6 +169,20 @@ __device__ __forceinline__ void shade_from_triangle(const FrameParams &fp, const
     shade(kp, v, px);
 }
 
+// Inclusive prefix sum over the 64 lanes of a wavefront with data-parallel-primitive moves: a Hillis-Steele scan
+// inside each row of 16 lanes (shifts by 1, 2, 4, 8; lanes without a source add 0), then the last lane of row 0 / 2
+// is added to row 1 / 3, then lane 31 (the sum of rows 0 and 1) to rows 2 and 3.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
+    int v = int(x);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return uint32_t(v);
+}
+
 // Scans rows [r0, r1] x columns [i0, i1] (at most 64 columns) of one sub-triangle into the LDS key tile.
 // Most cells of a cell range lie outside the triangle, and lanes of a wavefront walk ranges of very
 // different sizes, so the scan is split in two: (1) per row, each edge function is evaluated in
@@ -261,7 +275,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const flo
     __shared__ uint32_t big[kTileBigMax];
     // covered cells for the shading step; before that, staging for kTileStage swept records of 64 bytes
     __shared__ __align__(16) uint16_t covered[kTileCells > kTileStage * 32 ? kTileCells : kTileStage * 32];
-    __shared__ uint32_t n_list, n_big, n_cov;
+    __shared__ uint32_t n_big, n_cov;
+    __shared__ uint32_t cls_count[2][64];  // entries per work class in this filter step (two sets, used in turn)
     const uint32_t tid = threadIdx.x;
     // Workgroups are handed to the eight XCDs round-robin and each XCD has its own L2: the tiles of one
     // bin, which all read the bin's entry array, are given workgroup numbers that are equal modulo 8.
@@ -278,7 +293,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const flo
     const int jlo = fp.rows - fp.yb, jhi = fp.rows - 1 - fp.ya;  // window rows of the frame's strip, as in k_setup
     const BinState &st = state[fp.set];
     for (int c = int(tid); c < kTileCells; c += kTileThreads) keys[c] = kBackgroundKey;
-    if (tid == 0) { n_list = 0; n_big = 0; n_cov = 0; }
+    if (tid == 0) { n_big = 0; n_cov = 0; }
+    if (tid < 128u) cls_count[tid >> 6][tid & 63u] = 0;
     const uint32_t e_begin = st.start[bin];
     const uint32_t e_total = st.total[bin];
     const bool stored = e_begin <= entries_cap && e_total <= entries_cap - e_begin;  // same test as k_fill
@@ -288,6 +304,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const flo
     // filter the bin's entries by this tile's mask bit into the LDS list; whenever the list could
     // overflow on the next step (or at the end) rasterise what it holds
     // (kFilterBatch entries per lane and step, all loads in flight together: the step is one memory latency)
+    uint32_t nl = 0;  // length of the list (the same in every lane)
+    int cset = 0;
     for (uint32_t eb = e_begin;; eb += kTileThreads * kFilterBatch) {
         uint32_t ent[kFilterBatch];
 #pragma unroll
@@ -295,14 +313,31 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const flo
             const uint32_t e = eb + uint32_t(q) * uint32_t(kTileThreads) + tid;
             ent[q] = e < e_end ? entries[e] : 0u;  // mask 0 never matches
         }
+        // The step's matches go to the list ordered by work class (a counting sort: rank within the class from an
+        // LDS counter, start of the class from a scan over the counters), so that the 64 consecutive entries a
+        // wavefront takes below are triangles with the same number of rows and about the same width.  Every
+        // wavefront scans the counters for itself (lane c: class c), which keeps the list length in a register -
+        // the same in all lanes of the workgroup, as the flush decision below has to be: its block contains barriers.
+        const uint32_t id_mask = (1u << fp.id_bits) - 1u, cls_mask = (1u << fp.cls_bits) - 1u;
+        uint32_t rank[kFilterBatch];
 #pragma unroll
         for (int q = 0; q < kFilterBatch; q++)
-            if ((ent[q] >> kEntryMaskShift) & bit) list[atomicAdd(&n_list, 1u)] = ent[q] & kEntryLocMask;
+            if ((ent[q] >> kEntryMaskShift) & bit) rank[q] = atomicAdd(&cls_count[cset][(ent[q] >> fp.id_bits) & cls_mask], 1u);
         __syncthreads();
-        const uint32_t nl = n_list;
-        // every wavefront must have read n_list before any of them appends again (a wavefront that skips the
-        // raster block goes straight to the next step's appends): the flush decision below has to be the same
-        // in all of them, because the block contains barriers
+        {
+            const uint32_t v = cls_count[cset][tid & 63u];
+            const uint32_t inc = wave_inclusive_scan(v);
+            const uint32_t start = nl + inc - v;  // where this lane's class begins in the list
+#pragma unroll
+            for (int q = 0; q < kFilterBatch; q++) {
+                const uint32_t base = uint32_t(__shfl(int(start), int((ent[q] >> fp.id_bits) & cls_mask)));  // (all lanes take part)
+                if ((ent[q] >> kEntryMaskShift) & bit) list[base + rank[q]] = ent[q] & id_mask;
+            }
+            nl += uint32_t(__builtin_amdgcn_readlane(int(inc), 63));
+            // the other set was last read before the previous step's closing barrier and is next used after this one's
+            if (tid < 64u) cls_count[cset ^ 1][tid] = 0;
+            cset ^= 1;
+        }
         __syncthreads();
         const bool last = eb + kTileThreads * kFilterBatch >= e_end;
         if (nl + kTileThreads * kFilterBatch > uint32_t(kTileListMax) || last) {
@@ -384,7 +419,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const flo
                 __syncthreads();
             }
             __syncthreads();  // (every lane has read n_big by now)
-            if (tid == 0) { n_list = 0; n_big = 0; }
+            if (tid == 0) n_big = 0;
+            nl = 0;
             __syncthreads();
         }
         if (last) break;

@@ -265,11 +265,15 @@ int ar_frame_counters(ar_ctx *ctx, uint32_t out[8]);
  *   AR_OPT_POOL_RECORDS  capacity of the tiled path's (sub-triangle, bin) entry pool in entries;
  *                        0 (default) sizes it as 2 x triangles + 65536.
  *   AR_OPT_TILE_ROWS     height of the tiled path's tiles: 0 (default) picks 32 rows, or 16 or 8 when the frame
- *                        (a strip, a small grid) would otherwise have fewer than 512 tiles; 8, 16, 32 fix it. */
+ *                        (a strip, a small grid) would otherwise have fewer than 512 tiles; 8, 16, 32 fix it.
+ *   AR_OPT_WORK_CLASSES  1 (default): every tile orders its list of triangles by a work class (rows and width of the
+ *                        cell range, carried in spare bits of the bin entries) so that the lanes of a wavefront get
+ *                        triangles of one kind; 0: lists stay in entry order.  Same frames either way. */
 #define AR_OPT_PATH 1
 #define AR_OPT_POOL_RECORDS 2
 #define AR_OPT_OVERLAP 3
 #define AR_OPT_TILE_ROWS 4
+#define AR_OPT_WORK_CLASSES 5
 int ar_set_option(ar_ctx *ctx, int option, long long value);
 
 #ifdef __cplusplus

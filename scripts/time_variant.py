@@ -11,6 +11,8 @@ R = ar.Renderer(0)
 ar.scenes.upload(R, sc, mode_on=not os.environ.get("AR_NO_SMOOTHING"))
 if os.environ.get("AR_TILE_ROWS"):
     R.set_option("tile_rows", int(os.environ["AR_TILE_ROWS"]))
+if os.environ.get("AR_WORK_CLASSES"):
+    R.set_option("work_classes", int(os.environ["AR_WORK_CLASSES"]))
 res = {}
 for ov in (1, 0):
     R.set_option("overlap", ov)
