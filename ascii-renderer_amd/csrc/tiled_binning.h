@@ -50,6 +50,7 @@ constexpr int kSetupThreads = 256;    // k_setup / k_fill workgroup size
 constexpr uint32_t kMaxGroups = 1024;  // k_setup workgroups (rows of the count table)
 constexpr int kMaxPasses = 512;        // passes of 256 slots a k_setup workgroup makes at most (2^27 triangles / 1024 / 256)
 constexpr int kTileBigMax = 512;      // per-tile list of triangles swept cooperatively
+constexpr uint32_t kListSweep = 0x80000000u;  // mark in a tile's list: the entry is for the cooperative sweep (ids stay below 2^28)
 constexpr int kTileStage = 64;        // of which so many are staged in LDS at a time (64 B each, in the cell list's 4 KB)
 constexpr int kTileSmallCells = 64;   // cell-range area (inside the tile) one lane scans itself
 constexpr int kTileListMax = 2048;    // ids staged in LDS between the filter and the raster step

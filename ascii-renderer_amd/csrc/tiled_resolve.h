@@ -183,11 +183,13 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
     return uint32_t(v);
 }
 
-// Scans rows [r0, r1] x columns [i0, i1] (at most 64 columns) of one sub-triangle into the LDS key tile.
+// Scans rows [r0, r1] x columns [i0, i1] of one sub-triangle into the LDS key tile; the rows times the width
+// rounded up to a power of two must not exceed 64.
 // Most cells of a cell range lie outside the triangle, and lanes of a wavefront walk ranges of very
 // different sizes, so the scan is split in two: (1) per row, each edge function is evaluated in
 // binary32 and solved for the column where it crosses a conservative error band, which gives the
-// interval of columns that are not certainly outside - a run of bits in a 64-cell candidate mask;
+// interval of columns that are not certainly outside - a run of bits in a 64-cell candidate mask (row r gets the
+// 2^ls bits from r << ls, 2^ls the next power of two >= the width);
 // (2) only those cells pay for the binary64 evaluation that decides coverage and feeds the depth.
 // The result is exactly that of testing every cell in binary64.
 // Band: with a32 = fl(a), r32 = fl(b py + c), |a32 px + r32 - E| <= 2^-24 (|a| px + |r|) (1 + eps); a cell
@@ -195,36 +197,38 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
 // beyond the crossing column x of "a32 px + r32 = -band" by at least 0.8 band / |a32| >= 2^-19 |x|, far more
 // than the 2^-22 |x| the binary32 evaluation of x can be off.  Edges with a32 == 0 (or an overflowing
 // reciprocal) put no bound on the interval.
-__device__ __forceinline__ void raster_range(const FrameParams &fp, const Edges &ed, uint32_t key_low, int i0, int i1,
+// Registers are what limits the kernel around this function, so each pass holds only what it needs: pass (1) the
+// row coefficients b, c in binary64 and a in binary32 with its reciprocal; pass (2) a, b, c in binary64.  a is
+// therefore formed twice from the same operands (the same value both times: one rounding of an exact difference),
+// the second time behind a barrier the optimiser cannot see through - it would otherwise keep the first.
+__device__ __forceinline__ void raster_small(const FrameParams &fp, Screen sc, uint32_t key_low, int i0, int i1,
                                              int r0, int r1, int tx0, int tr0, uint64_t *keys) {
     constexpr float kBand = 1.0f / 262144.0f;  // 2^-18
-    const float a32[3] = {float(ed.a[0]), float(ed.a[1]), float(ed.a[2])};
-    // (hardware reciprocal: 1 ulp, inside the error budget above)
-    const float inv_a[3] = {__builtin_amdgcn_rcpf(a32[0]), __builtin_amdgcn_rcpf(a32[1]), __builtin_amdgcn_rcpf(a32[2])};
-    // coverage is E_k >= thr_k with thr_k = 0 on edges that own their boundary and the smallest positive
-    // binary64 otherwise (E_k > 0): the same decision as edge_inside with one comparison per edge
-    double thr[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-        thr[k] = (ed.a[k] > 0.0 || (ed.a[k] == 0.0 && ed.b[k] > 0.0)) ? 0.0 : 4.9406564584124654e-324;
-    // (the band's |a32| px_max term, already times 2^-18: a power of two, so scaling first changes nothing)
-    const float apx[3] = {kBand * (fabsf(a32[0]) * float(i1 + 1)), kBand * (fabsf(a32[1]) * float(i1 + 1)),
-                          kBand * (fabsf(a32[2]) * float(i1 + 1))};
-    // a chunk's candidate mask gives each row 2^ls bits, the next power of two >= the width (<= 64: a tile's): bit
-    // k is row k >> ls, column k & (2^ls - 1)
     const int w = i1 - i0 + 1;
     const int ls = w <= 1 ? 0 : 32 - __clz(w - 1);
-    const int rows_per_chunk = 64 >> ls;
-    const float flo = float(i0), fhi = float(i1);
-    for (int rc = r0; rc <= r1; rc += rows_per_chunk) {
-        const int rc1 = min(rc + rows_per_chunk - 1, r1);
-        unsigned long long cand = 0ull;
-        for (int rr = rc; rr <= rc1; rr++) {
+    double b[3], c[3];
+    unsigned long long cand = 0ull;
+    {
+        float a32[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int p = (k + 1) % 3, q = (k + 2) % 3;
+            a32[k] = float(diff_of_products(sc.Y[p], sc.W[q], sc.Y[q], sc.W[p]));
+            b[k] = diff_of_products(sc.X[q], sc.W[p], sc.X[p], sc.W[q]);
+            c[k] = diff_of_products(sc.X[p], sc.Y[q], sc.X[q], sc.Y[p]);
+        }
+        // (hardware reciprocal: 1 ulp, inside the error budget above)
+        const float inv_a[3] = {__builtin_amdgcn_rcpf(a32[0]), __builtin_amdgcn_rcpf(a32[1]), __builtin_amdgcn_rcpf(a32[2])};
+        // (the band's |a32| px_max term, already times 2^-18: a power of two, so scaling first changes nothing)
+        const float apx[3] = {kBand * (fabsf(a32[0]) * float(i1 + 1)), kBand * (fabsf(a32[1]) * float(i1 + 1)),
+                              kBand * (fabsf(a32[2]) * float(i1 + 1))};
+        const float flo = float(i0), fhi = float(i1);
+        for (int rr = r0; rr <= r1; rr++) {
             const double py = double(fp.rows - 1 - rr) + 0.5;
             float lo = flo, hi = fhi;  // candidate columns, as cell indices
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const float r32 = float(__builtin_fma(ed.b[k], py, ed.c[k]));  // (fused: closer to b py + c than the bound assumes)
+                const float r32 = float(__builtin_fma(b[k], py, c[k]));  // (fused: closer to b py + c than the bound assumes)
                 const float band = __builtin_fmaf(kBand, fabsf(r32), apx[k]);
                 const float x = __builtin_fmaf(-band - r32, inv_a[k], -0.5f);  // crossing column as a cell index (fused: nearer the true crossing)
                 lo = fmaxf(lo, a32[k] > 0.0f ? x : flo);
@@ -235,28 +239,46 @@ __device__ __forceinline__ void raster_range(const FrameParams &fp, const Edges 
             const int n = ihi - ilo + 1;
             if (n <= 0) continue;
             const unsigned long long run = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
-            cand |= run << (((rr - rc) << ls) + (ilo - i0));
-        }
-        uint32_t clo = uint32_t(cand), chi = uint32_t(cand >> 32);
-        while (clo | chi) {
-            int k;
-            if (clo) { k = __ffs(int(clo)) - 1; clo &= clo - 1u; }
-            else { k = 31 + __ffs(int(chi)); chi &= chi - 1u; }
-            const int rr = rc + (k >> ls), i = i0 + (k & ((1 << ls) - 1));
-            const double px = double(i) + 0.5, py = double(fp.rows - 1 - rr) + 0.5;
-            const double E0 = ed.a[0] * px + (ed.b[0] * py + ed.c[0]);
-            const double E1 = ed.a[1] * px + (ed.b[1] * py + ed.c[1]);
-            const double E2 = ed.a[2] * px + (ed.b[2] * py + ed.c[2]);
-            const float f0 = float(E0), f1 = float(E1), f2 = float(E2);
-            const float den = (f0 * ed.W[0] + f1 * ed.W[1]) + f2 * ed.W[2];
-            const float num = (f0 * ed.Z[0] + f1 * ed.Z[1]) + f2 * ed.Z[2];
-            const float zw = (num / den) * 0.5f + 0.5f;
-            if ((E0 >= thr[0]) & (E1 >= thr[1]) & (E2 >= thr[2]) & (zw >= 0.0f) & (zw < 1.0f))
-                atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
-                          (unsigned long long)make_key(zw, key_low));
+            cand |= run << (((rr - r0) << ls) + (ilo - i0));
         }
     }
+#pragma unroll
+    for (int k = 0; k < 3; k++) asm volatile("" : "+v"(sc.Y[k]), "+v"(sc.W[k]));
+    // coverage is E_k >= thr_k with thr_k = 0 on edges that own their boundary and the smallest positive
+    // binary64 otherwise (E_k > 0): the same decision as edge_inside with one comparison per edge
+    double a[3], thr[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int p = (k + 1) % 3, q = (k + 2) % 3;
+        a[k] = diff_of_products(sc.Y[p], sc.W[q], sc.Y[q], sc.W[p]);
+        thr[k] = (a[k] > 0.0 || (a[k] == 0.0 && b[k] > 0.0)) ? 0.0 : 4.9406564584124654e-324;
+    }
+    uint32_t clo = uint32_t(cand), chi = uint32_t(cand >> 32);
+    while (clo | chi) {
+        int k;
+        if (clo) { k = __ffs(int(clo)) - 1; clo &= clo - 1u; }
+        else { k = 31 + __ffs(int(chi)); chi &= chi - 1u; }
+        const int rr = r0 + (k >> ls), i = i0 + (k & ((1 << ls) - 1));
+        const double px = double(i) + 0.5, py = double(fp.rows - 1 - rr) + 0.5;
+        const double E0 = a[0] * px + (b[0] * py + c[0]);
+        const double E1 = a[1] * px + (b[1] * py + c[1]);
+        const double E2 = a[2] * px + (b[2] * py + c[2]);
+        const float f0 = float(E0), f1 = float(E1), f2 = float(E2);
+        const float den = (f0 * sc.W[0] + f1 * sc.W[1]) + f2 * sc.W[2];
+        const float num = (f0 * sc.Z[0] + f1 * sc.Z[1]) + f2 * sc.Z[2];
+        const float zw = (num / den) * 0.5f + 0.5f;
+        if (int(E0 >= thr[0]) & int(E1 >= thr[1]) & int(E2 >= thr[2]) & int(zw >= 0.0f) & int(zw < 1.0f))
+            atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
+                      (unsigned long long)make_key(zw, key_low));
+    }
 }
+
+// Where the entry with place p in the order of work classes sits in a tile's list: every second run of 256 places is
+// stored back to front.  The lanes of the workgroup take the list 256 places at a time, first wavefront first; with the
+// list in ascending order of work that would give the lightest quarter of every run to the first wavefront and the
+// heaviest to the last, this way light and heavy quarters alternate.  (Its own inverse.  A list that ends inside a
+// reversed run leaves the head of that run empty: slot s holds an entry if and only if list_slot(s) < length.)
+__device__ __forceinline__ uint32_t list_slot(uint32_t p) { return p ^ ((0u - ((p >> 8) & 1u)) & 255u); }
 
 // TEX: the frame samples an atlas (texel coordinates and atlas are only read then).  SH: log2 of the tile height.
 template <bool TEX, int SH>
@@ -275,7 +297,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const flo
     __shared__ uint32_t big[kTileBigMax];
     // covered cells for the shading step; before that, staging for kTileStage swept records of 64 bytes
     __shared__ __align__(16) uint16_t covered[kTileCells > kTileStage * 32 ? kTileCells : kTileStage * 32];
-    __shared__ uint32_t n_big, n_cov;
+    __shared__ uint32_t n_big, n_cov, n_marked;
     __shared__ uint32_t cls_count[2][64];  // entries per work class in this filter step (two sets, used in turn)
     const uint32_t tid = threadIdx.x;
     // Workgroups are handed to the eight XCDs round-robin and each XCD has its own L2: the tiles of one
@@ -293,7 +315,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const flo
     const int jlo = fp.rows - fp.yb, jhi = fp.rows - 1 - fp.ya;  // window rows of the frame's strip, as in k_setup
     const BinState &st = state[fp.set];
     for (int c = int(tid); c < kTileCells; c += kTileThreads) keys[c] = kBackgroundKey;
-    if (tid == 0) { n_big = 0; n_cov = 0; }
+    if (tid == 0) { n_big = 0; n_cov = 0; n_marked = 0; }
     if (tid < 128u) cls_count[tid >> 6][tid & 63u] = 0;
     const uint32_t e_begin = st.start[bin];
     const uint32_t e_total = st.total[bin];
@@ -331,7 +353,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const flo
 #pragma unroll
             for (int q = 0; q < kFilterBatch; q++) {
                 const uint32_t base = uint32_t(__shfl(int(start), int((ent[q] >> fp.id_bits) & cls_mask)));  // (all lanes take part)
-                if ((ent[q] >> kEntryMaskShift) & bit) list[base + rank[q]] = ent[q] & id_mask;
+                if ((ent[q] >> kEntryMaskShift) & bit) list[list_slot(base + rank[q])] = ent[q] & id_mask;
             }
             nl += uint32_t(__builtin_amdgcn_readlane(int(inc), 63));
             // the other set was last read before the previous step's closing barrier and is next used after this one's
@@ -341,8 +363,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const flo
         __syncthreads();
         const bool last = eb + kTileThreads * kFilterBatch >= e_end;
         if (nl + kTileThreads * kFilterBatch > uint32_t(kTileListMax) || last) {
-            // sub-triangles with a small cell range inside the tile: one lane each; others -> sweep list
-            // (a lane's next triangle record is fetched while it works on the current one).
+            // sub-triangles with a small cell range inside the tile: one lane each; others are marked in the list for
+            // the sweep below (a lane's next triangle record is fetched while it works on the current one).
             // A short list leaves most lanes without a triangle, and the few that have one walk their rows one
             // after the other: then 2, 4, 8 or 16 neighbouring lanes share a triangle - each redoes its setup (for
             // nothing: the wavefront executes those instructions anyway) and takes an equal share of its rows.
@@ -350,12 +372,14 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const flo
             while (gshift < 4 && (nl << (gshift + 1)) <= uint32_t(kTileThreads)) gshift++;
             const uint32_t per_round = uint32_t(kTileThreads) >> gshift, first = tid >> gshift;
             const int part = int(tid & ((1u << gshift) - 1u));
+            const uint32_t n_rounds = (nl + per_round - 1u) / per_round;
             TriStatic ahead;
-            if (first < nl) ahead = tri[list[first] >> 1];
-            for (uint32_t r = first; r < nl; r += per_round) {
+            if (first < nl) ahead = tri[list[first] >> 1];  // (the first run of 256 is in order)
+            for (uint32_t r = first; r < n_rounds * per_round; r += per_round) {
+                if (list_slot(r) >= nl) continue;  // (an empty slot: only in the last round)
                 const uint32_t id = list[r];
                 const TriStatic ts = ahead;
-                if (r + per_round < nl) ahead = tri[list[r + per_round] >> 1];
+                if (list_slot(r + per_round) < nl) ahead = tri[list[r + per_round] >> 1];
                 Screen sc;
                 bool clipped;
                 int ci0, ci1, cj0, cj1;
@@ -363,65 +387,68 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const flo
                 if (!cell_range(sc.X, sc.Y, sc.W, fp.cols, jlo, jhi, ci0, ci1, cj0, cj1)) continue;  // (binned: never empty)
                 const int i0 = max(ci0, tx0), i1 = min(ci1, tx1);
                 int r0 = max(fp.rows - 1 - cj1, tr0), r1 = min(fp.rows - 1 - cj0, tr1);
-                if ((i1 - i0 + 1) * (r1 - r0 + 1) > (kTileSmallCells << gshift)) {
-                    uint32_t slot = 0;
-                    if (part == 0) slot = atomicAdd(&n_big, 1u);
-                    slot = uint32_t(__shfl(int(slot), int(tid & 63u) & ~((1 << gshift) - 1)));  // the sharing lanes are neighbours in one wavefront
-                    if (slot < uint32_t(kTileBigMax)) {
-                        if (part == 0) big[slot] = id;
-                        continue;
-                    }
-                    // list full: these lanes scan the range themselves (slow but correct)
+                // a lane's share of the rows, times the width rounded up to a power of two, has to fit the 64-bit
+                // candidate mask of raster_small
+                const int len = (r1 - r0 + (1 << gshift)) >> gshift;
+                const int w = i1 - i0 + 1;
+                if ((len << (w <= 1 ? 0 : 32 - __clz(w - 1))) > kTileSmallCells) {
+                    if (part == 0) { list[r] = id | kListSweep; n_marked = 1u; }  // (its own entry: nobody else reads or writes it in this loop)
+                    continue;
                 }
-                if (gshift) {  // this lane's share of the rows
-                    const int len = (r1 - r0 + (1 << gshift)) >> gshift;
-                    r0 += part * len;
-                    r1 = min(r0 + len - 1, r1);
-                    if (r0 > r1) continue;
-                }
-                Edges ed;
-                edges_from_screen(sc, ed);
-                raster_range(fp, ed, tile_key_low(2u * (ts.flags >> kFlagBits) + (id & 1u), clipped), i0, i1, r0, r1, tx0, tr0, keys);
+                r0 += part * len;  // this lane's share of the rows
+                r1 = min(r0 + len - 1, r1);
+                if (r0 > r1) continue;
+                const uint32_t key_id = 2u * (ts.flags >> kFlagBits) + (id & 1u);
+                raster_small(fp, sc, tile_key_low(key_id, clipped), i0, i1, r0, r1, tx0, tr0, keys);
             }
             __syncthreads();
-            // sweep list: the triangle records are brought into LDS 64 at a time (one fetch latency per batch instead
-            // of one per triangle), then every wavefront sweeps a triangle of its own, 64 cells per step
-            const uint32_t nb = min(n_big, uint32_t(kTileBigMax));
+            // sweep: the marked entries are collected 256 list places at a time; when more than half of the sweep list
+            // is taken (or at the end) their triangle records are brought into LDS 64 at a time (one fetch latency per
+            // batch instead of one per triangle), and every wavefront sweeps a triangle of its own, 64 cells per step
             TriStatic *stage = reinterpret_cast<TriStatic *>(covered);  // (the cell list is not in use before the raster step ends)
-            for (uint32_t b0 = 0; b0 < nb; b0 += kTileStage) {
-                const uint32_t ns = min(uint32_t(kTileStage), nb - b0);
-                if (tid < ns) stage[tid] = tri[big[b0 + tid] >> 1];
+            const uint32_t sweep_end = n_marked != 0u ? nl : 0u;  // (nothing marked - the usual case at a million small triangles: no pass over the list)
+            for (uint32_t s0 = 0; s0 < sweep_end; s0 += kTileThreads) {
+                const uint32_t marked = list_slot(s0 + tid) < nl ? list[s0 + tid] : 0u;
+                if (marked & kListSweep) big[atomicAdd(&n_big, 1u)] = marked & ~kListSweep;
                 __syncthreads();
-                for (uint32_t q = tid >> 6; q < ns; q += kTileThreads / 64) {
-                    const uint32_t id = big[b0 + q];
-                    const uint32_t key_id = 2u * (stage[q].flags >> kFlagBits) + (id & 1u);
-                    float p[9];
+                const uint32_t nb = n_big;  // (at most kTileBigMax: it was at most half of that before this step)
+                __syncthreads();            // (every lane has read it before it changes again)
+                if (tid == 0) n_marked = 0;  // (read by all before the barriers above; next written after the barriers below or the next step's)
+                if (nb == 0u || (nb <= uint32_t(kTileBigMax - kTileThreads) && s0 + kTileThreads < nl)) continue;
+                for (uint32_t b0 = 0; b0 < nb; b0 += kTileStage) {
+                    const uint32_t ns = min(uint32_t(kTileStage), nb - b0);
+                    if (tid < ns) stage[tid] = tri[big[b0 + tid] >> 1];
+                    __syncthreads();
+                    for (uint32_t q = tid >> 6; q < ns; q += kTileThreads / 64) {
+                        const uint32_t id = big[b0 + q];
+                        const uint32_t key_id = 2u * (stage[q].flags >> kFlagBits) + (id & 1u);
+                        float p[9];
 #pragma unroll
-                    for (int k = 0; k < 9; k++) p[k] = stage[q].p[k];
-                    Screen sc;
-                    bool clipped;
-                    int ci0, ci1, cj0, cj1;
-                    binned_triangle_screen(fp, p, id & 1u, sc, clipped);
-                    if (!cell_range(sc.X, sc.Y, sc.W, fp.cols, jlo, jhi, ci0, ci1, cj0, cj1)) continue;
-                    const int i0 = max(ci0, tx0), i1 = min(ci1, tx1);
-                    const int r0 = max(fp.rows - 1 - cj1, tr0), r1 = min(fp.rows - 1 - cj0, tr1);
-                    const int w = i1 - i0 + 1, n = w * (r1 - r0 + 1);
-                    Edges ed;
-                    edges_from_screen(sc, ed);
-                    for (int k = int(tid & 63u); k < n; k += 64) {
-                        const int dr = k / w, i = i0 + (k - dr * w), rr = r0 + dr;
-                        float f[3], zw;
-                        if (cover(ed, i, fp.rows - 1 - rr, f, zw))
-                            atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
-                                      (unsigned long long)make_key(zw, tile_key_low(key_id, clipped)));
+                        for (int k = 0; k < 9; k++) p[k] = stage[q].p[k];
+                        Screen sc;
+                        bool clipped;
+                        int ci0, ci1, cj0, cj1;
+                        binned_triangle_screen(fp, p, id & 1u, sc, clipped);
+                        if (!cell_range(sc.X, sc.Y, sc.W, fp.cols, jlo, jhi, ci0, ci1, cj0, cj1)) continue;
+                        const int i0 = max(ci0, tx0), i1 = min(ci1, tx1);
+                        const int r0 = max(fp.rows - 1 - cj1, tr0), r1 = min(fp.rows - 1 - cj0, tr1);
+                        const int w = i1 - i0 + 1, n = w * (r1 - r0 + 1);
+                        Edges ed;
+                        edges_from_screen(sc, ed);
+                        for (int k = int(tid & 63u); k < n; k += 64) {
+                            const int dr = k / w, i = i0 + (k - dr * w), rr = r0 + dr;
+                            float f[3], zw;
+                            if (cover(ed, i, fp.rows - 1 - rr, f, zw))
+                                atomicMin(reinterpret_cast<unsigned long long *>(&keys[(rr - tr0) * kTileW + (i - tx0)]),
+                                          (unsigned long long)make_key(zw, tile_key_low(key_id, clipped)));
+                        }
                     }
+                    __syncthreads();
                 }
+                if (tid == 0) n_big = 0;
                 __syncthreads();
             }
-            __syncthreads();  // (every lane has read n_big by now)
-            if (tid == 0) n_big = 0;
             nl = 0;
-            __syncthreads();
         }
         if (last) break;
     }
