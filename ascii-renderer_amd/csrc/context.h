@@ -379,16 +379,16 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
         uint32_t *blocksum = dircount + ctx->dircount_cap;
         {
             Stamper s(ctx, K_SETUP, fs);
-            k_setup<<<fp.n_groups, kSetupThreads, 0, fs>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_box, ctx->d_surv[set], ctx->d_sid[set],
+            k_setup<<<fp.n_groups, kSetupThreads, nbins * sizeof(uint32_t), fs>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_box, ctx->d_surv[set], ctx->d_sid[set],
                                                          ctx->d_surv_count[set], dircount);
         }
         {
             Stamper s(ctx, K_BINSCAN, fs);
-            k_binscan<<<dim3(unsigned((nbins + 63) / 64), 16), 1024, 0, fs>>>(fp, dircount, blocksum);
+            k_binscan<<<dim3(unsigned((nbins + 63) / 64), 16), 64 * kScanWaves, 0, fs>>>(fp, dircount, blocksum);
         }
         {
             Stamper s(ctx, K_FILL, fs);
-            k_fill<<<fp.n_groups, kSetupThreads, 0, fs>>>(fp, ctx->d_tri, ctx->d_surv[set], ctx->d_sid[set], ctx->d_surv_count[set], dircount, blocksum,
+            k_fill<<<fp.n_groups, kSetupThreads, nbins * 2 * sizeof(uint32_t) + ((nbins + 3) & ~size_t(3)), fs>>>(fp, ctx->d_tri, ctx->d_surv[set], ctx->d_sid[set], ctx->d_surv_count[set], dircount, blocksum,
                                                         ctx->d_state, ctx->d_entries[set], ctx->pool_cap, ctx->d_vis[set]);
         }
         {

@@ -430,7 +430,10 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const f
                                                          const float *__restrict__ box, uint2 *__restrict__ surv,
                                                          uint32_t *__restrict__ sid, uint32_t *__restrict__ surv_count,
                                                          uint32_t *__restrict__ dircount) {
-    __shared__ uint32_t hist[kMaxBins];
+    // (LDS sized by the launch to the frame's bins, not to the most a frame can have: the frame's kernels run beside
+    // the tile resolve of the frame before, which leaves them a fifth of a compute unit's LDS)
+    extern __shared__ uint32_t bins_lds[];
+    uint32_t *hist = bins_lds;  // [nbins]
     __shared__ uint32_t s_wave[kSetupThreads / 64];
     __shared__ uint32_t outside[kMaxPasses];  // per pass: the frustum planes that all eight corners of its box lie beyond
     const uint32_t tid = threadIdx.x;
@@ -511,18 +514,23 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const f
 
 // Column-wise exclusive prefix of the count table over the k_setup workgroups, in two levels.  The
 // table's rows are cut into 16 row blocks; workgroup (x, y) takes bins [64x, 64x + 64) of row block y
-// (its 16 wavefronts split the block's rows), rewrites table[g][b] as "entries of bin b that belong to
+// (its four wavefronts split the block's rows), rewrites table[g][b] as "entries of bin b that belong to
 // earlier workgroups of the same row block" and stores the block's total in blocksum[y][b].  k_fill
 // adds the totals of the earlier row blocks.  No global atomics, and the layout of every bin's entry
 // array is the same on every run.
-__global__ __launch_bounds__(1024) void k_binscan(FrameParams fp, uint32_t *__restrict__ table, uint32_t *__restrict__ blocksum) {
-    __shared__ uint32_t part[16][64];
+// Four wavefronts per workgroup, not sixteen: the frame's kernels share the GPU with the tile resolve of the frame
+// before, which leaves room for one or two wavefronts per SIMD - a workgroup that needs four of them on one
+// compute unit waits until tiles there have finished (measured: 20 us, for every third frame).
+constexpr int kScanWaves = 4;
+static_assert(kMaxGroups <= 16u * 16u * kScanWaves, "a wavefront of k_binscan takes at most 16 rows of its row block");
+__global__ __launch_bounds__(64 * kScanWaves) void k_binscan(FrameParams fp, uint32_t *__restrict__ table, uint32_t *__restrict__ blocksum) {
+    __shared__ uint32_t part[kScanWaves][64];
     const int nbins = fp.nbx * fp.nby;
     const int lane = int(threadIdx.x & 63u), w = int(threadIdx.x >> 6);
     const int b = int(blockIdx.x) * 64 + lane;
     const uint32_t rows_per_block = (fp.n_groups + 15u) / 16u;
     const uint32_t blk0 = min(uint32_t(blockIdx.y) * rows_per_block, fp.n_groups), blk1 = min(blk0 + rows_per_block, fp.n_groups);
-    const uint32_t rows_per_wave = (rows_per_block + 15u) / 16u;  // <= 16 (at most 4096 k_setup workgroups)
+    const uint32_t rows_per_wave = (rows_per_block + uint32_t(kScanWaves) - 1u) / uint32_t(kScanWaves);  // <= 16 (at most 1024 k_setup workgroups)
     const uint32_t g0 = min(blk0 + uint32_t(w) * rows_per_wave, blk1), g1 = min(g0 + rows_per_wave, blk1);
     uint32_t v[16], sum = 0;
 #pragma unroll
@@ -534,7 +542,7 @@ __global__ __launch_bounds__(1024) void k_binscan(FrameParams fp, uint32_t *__re
     __syncthreads();
     uint32_t run = 0, tot = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < kScanWaves; k++) {
         const uint32_t x = part[k][lane];
         if (k < w) run += x;
         tot += x;
@@ -561,11 +569,12 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Tr
                                                         const uint32_t *__restrict__ blocksum, BinState *__restrict__ state,
                                                         uint32_t *__restrict__ entries, uint32_t entries_cap,
                                                         uint64_t *__restrict__ vis) {
-    __shared__ uint32_t base[kMaxBins], cnt[kMaxBins];  // cnt holds the bin totals until the offsets are done
-    __shared__ uint8_t fits[kMaxBins];
-    __shared__ uint32_t s_wave[kSetupThreads / 64];
+    extern __shared__ uint32_t bins_lds[];  // (sized by the launch to the frame's bins, as in k_setup)
     const uint32_t tid = threadIdx.x;
     const int nbins = fp.nbx * fp.nby;
+    uint32_t *base = bins_lds, *cnt = bins_lds + nbins;  // cnt holds the bin totals until the offsets are done
+    uint8_t *fits = reinterpret_cast<uint8_t *>(bins_lds + 2 * nbins);
+    __shared__ uint32_t s_wave[kSetupThreads / 64];
     BinState &st = state[fp.set];
     const uint32_t rows_per_block = (fp.n_groups + 15u) / 16u;
     const uint32_t my_block = blockIdx.x / rows_per_block;
