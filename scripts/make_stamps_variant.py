@@ -12,10 +12,10 @@ def rep(a, b):
     s = s.replace(a, b)
 rep("namespace {\n\nconstexpr uint64_t kBackgroundKey", "__device__ unsigned long long g_stamps[8192 * 8];\n#define STAMP(k) do { if (tid == 0) g_stamps[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)\nnamespace {\n\nconstexpr uint64_t kBackgroundKey")
 
-rep("    for (int c = int(tid); c < kTileCells; c += 256) keys[c] = kBackgroundKey;\n    if (tid == 0) { n_list = 0; n_big = 0; n_cov = 0; }", "    STAMP(0);\n    for (int c = int(tid); c < kTileCells; c += 256) keys[c] = kBackgroundKey;\n    if (tid == 0) { n_list = 0; n_big = 0; n_cov = 0; }")
-rep("        if (nl + 256 * kFilterBatch > uint32_t(kTileListMax) || last) {\n", "        if (nl + 256 * kFilterBatch > uint32_t(kTileListMax) || last) {\n            STAMP(1); if (tid == 0) g_stamps[blockIdx.x * 8 + 7] = (unsigned long long)nl << 40 | (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 32 | (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);\n")
-rep("            __syncthreads();\n            // sweep list: the triangle records are brought into LDS", "            __syncthreads();\n            STAMP(2);\n            // sweep list: the triangle records are brought into LDS")
-rep("            __syncthreads();  // (every lane has read n_big by now)\n            if (tid == 0) { n_list = 0; n_big = 0; }", "            __syncthreads();\n            STAMP(3);\n            if (tid == 0) { n_list = 0; n_big = 0; }")
+rep("    for (int c = int(tid); c < kTileCells; c += kTileThreads) keys[c] = kBackgroundKey;\n    if (tid == 0) { n_big = 0; n_cov = 0; n_marked = 0; }", "    STAMP(0);\n    for (int c = int(tid); c < kTileCells; c += kTileThreads) keys[c] = kBackgroundKey;\n    if (tid == 0) { n_big = 0; n_cov = 0; n_marked = 0; }")
+rep("        if (nl + kTileThreads * kFilterBatch > uint32_t(kTileListMax) || last) {\n", "        if (nl + kTileThreads * kFilterBatch > uint32_t(kTileListMax) || last) {\n            STAMP(1); if (tid == 0) g_stamps[blockIdx.x * 8 + 7] = (unsigned long long)nl << 40 | (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 32 | (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);\n")
+rep("            __syncthreads();\n            // sweep: the marked entries are collected", "            __syncthreads();\n            STAMP(2);\n            // sweep: the marked entries are collected")
+rep("            nl = 0;\n        }\n        if (last) break;", "            STAMP(3);\n            nl = 0;\n        }\n        if (last) break;")
 rep("    __syncthreads();\n    const uint32_t nc = n_cov;", "    __syncthreads();\n    STAMP(4);\n    const uint32_t nc = n_cov;")
 rep("    __syncthreads();\n\n    // colour and ramp index of a resolved key", "    __syncthreads();\n    STAMP(5);\n\n    // colour and ramp index of a resolved key")
 rep("            reinterpret_cast<uint32_t *>(ridx)[cell >> 2] = ri4;\n        }\n        return;", "            reinterpret_cast<uint32_t *>(ridx)[cell >> 2] = ri4;\n        }\n        STAMP(6);\n        return;")
