@@ -370,12 +370,28 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const flo
             // nothing: the wavefront executes those instructions anyway) and takes an equal share of its rows.
             int gshift = 0;
             while (gshift < 4 && (nl << (gshift + 1)) <= uint32_t(kTileThreads)) gshift++;
-            const uint32_t per_round = uint32_t(kTileThreads) >> gshift, first = tid >> gshift;
-            const int part = int(tid & ((1u << gshift) - 1u));
+            const uint32_t per_round = uint32_t(kTileThreads) >> gshift;  // groups of sharing lanes: entries taken per round
+            uint32_t first = tid >> gshift;
+            uint32_t my_part = tid & ((1u << gshift) - 1u);
             const uint32_t n_rounds = (nl + per_round - 1u) / per_round;
+            // One round and groups to spare (a list between half and all of what a round takes): the spare groups join
+            // the last entries of the list - the heaviest, the list being in order of work - whose rows are then split
+            // among twice as many lanes.  Entry e gets the spare group 2 nl - 1 - e.
+            uint32_t spare_from = ~0u;  // entries from here on have two groups (none in a list of several rounds)
+            if (n_rounds == 1u) {
+                spare_from = 2u * nl > per_round ? 2u * nl - per_round : 0u;
+                if (first >= nl) {
+                    first = (2u * nl - 1u - first) & 0xFFFFu;  // (beyond 2 nl - 1 this wraps to a place past the list: no entry)
+                    my_part += 1u << gshift;
+                }
+            }
             TriStatic ahead;
             if (first < nl) ahead = tri[list[first] >> 1];  // (the first run of 256 is in order)
-            for (uint32_t r = first; r < n_rounds * per_round; r += per_round) {
+            // (list place and the lane's number among the lanes of its entry travel in one register: they are few bits each,
+            // and registers are what limits this kernel)
+            for (uint32_t rp = first | (my_part << 16); (rp & 0xFFFFu) < n_rounds * per_round; rp += per_round) {
+                const uint32_t r = rp & 0xFFFFu;
+                const int part = int(rp >> 16);
                 if (list_slot(r) >= nl) continue;  // (an empty slot: only in the last round)
                 const uint32_t id = list[r];
                 const TriStatic ts = ahead;
@@ -389,7 +405,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const flo
                 int r0 = max(fp.rows - 1 - cj1, tr0), r1 = min(fp.rows - 1 - cj0, tr1);
                 // a lane's share of the rows, times the width rounded up to a power of two, has to fit the 64-bit
                 // candidate mask of raster_small
-                const int len = (r1 - r0 + (1 << gshift)) >> gshift;
+                const int pshift = gshift + (r >= spare_from ? 1 : 0);  // log2 of the lanes that share this entry
+                const int len = (r1 - r0 + (1 << pshift)) >> pshift;
                 const int w = i1 - i0 + 1;
                 if ((len << (w <= 1 ? 0 : 32 - __clz(w - 1))) > kTileSmallCells) {
                     if (part == 0) { list[r] = id | kListSweep; n_marked = 1u; }  // (its own entry: nobody else reads or writes it in this loop)

@@ -4,8 +4,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ar = importlib.import_module("ascii-renderer_amd")
 ar.binding.LIB_PATH = os.environ["AR_LIB"]
-which = os.environ.get("AR_SCENE", "c3")     # c3 (default) | ico (C2) | cube (C1)
-sc = {"c3": lambda: ar.scenes.random_scene(1000000, 1920, 1080), "ico": ar.scenes.icosphere_scene, "cube": ar.scenes.cube_scene}[which]()
+which = os.environ.get("AR_SCENE", "c3")     # c3 (default) | c4 | c5 | ico (C2) | cube (C1)
+sc = {"c3": lambda: ar.scenes.random_scene(1000000, 1920, 1080), "c4": lambda: ar.scenes.random_scene(1000000, 3840, 2160), "c5": lambda: ar.scenes.random_scene(10000000, 1920, 1080, seed=0xA5C12, point_lights=True), "ico": ar.scenes.icosphere_scene, "cube": ar.scenes.cube_scene}[which]()
 R = ar.Renderer(0)
 R.set_option("overlap", 0)
 ar.scenes.upload(R, sc)
