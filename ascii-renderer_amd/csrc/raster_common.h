@@ -164,10 +164,12 @@ struct Screen {
 // False when the triangle cannot produce fragments because a vertex is non-finite or has w <= 0.
 __device__ __forceinline__ bool to_screen(const float (&c0)[4], const float (&c1)[4], const float (&c2)[4], float hw,
                                           float hh, Screen &s) {
-    bool ok = true;
+    // all twelve coordinates finite: x * 0 is a zero for finite x and a NaN otherwise, so the sum of the twelve products
+    // is zero exactly when all are finite (twelve plain multiply-adds and one comparison instead of twelve class tests)
+    float z = 0.0f;
 #pragma unroll
-    for (int q = 0; q < 4; q++) ok = ok && isfinite(c0[q]) && isfinite(c1[q]) && isfinite(c2[q]);
-    ok = ok && (c0[3] > 0.0f) && (c1[3] > 0.0f) && (c2[3] > 0.0f);
+    for (int q = 0; q < 4; q++) z = __builtin_fmaf(c2[q], 0.0f, __builtin_fmaf(c1[q], 0.0f, __builtin_fmaf(c0[q], 0.0f, z)));
+    const bool ok = (z == 0.0f) && (c0[3] > 0.0f) && (c1[3] > 0.0f) && (c2[3] > 0.0f);
     if (!ok) return false;
     s.W[0] = c0[3]; s.W[1] = c1[3]; s.W[2] = c2[3];
     s.Z[0] = c0[2]; s.Z[1] = c1[2]; s.Z[2] = c2[2];
