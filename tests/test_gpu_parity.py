@@ -153,7 +153,7 @@ def test_multi_gpu_configs_cut_into_strips(pkg, oracle, config):
 
 def test_thousands_of_triangles_in_one_tile(pkg, oracle, R):
     """24000 triangles of all sizes heaped on a patch of about 30 x 30 cells: the tile's work list fills and is
-    rasterised several times over, and the list of swept triangles overflows into the per-lane scan."""
+    rasterised several times over, and the triangles marked for the cooperative sweep are collected in several batches."""
     rng = np.random.default_rng(5)
     T = 24000
     centre = np.array([5.0, 0.3, 0.2]) + rng.uniform(-0.5, 0.5, size=(T, 1, 3)) * np.array([0.3, 1.0, 1.0])
@@ -167,6 +167,25 @@ def test_thousands_of_triangles_in_one_tile(pkg, oracle, R):
             _check(pkg, oracle, R, sc)
         if R.path_name == "tiled" and cols == 320:
             assert R.frame_counters()["bin_records"] > 3 * 2048      # (one bin holds nearly all of them)
+
+
+def test_tile_lists_of_every_length_with_and_without_work_classes(pkg, oracle, R):
+    """The lane loop of the tile resolve has a regime per list length: lanes sharing a triangle (short lists), spare lane
+    groups joining the heaviest triangles (between half a round and a round), several rounds with every second run of
+    256 stored back to front, and lists longer than the staging area.  A cloud of small triangles over four tiles,
+    sized to put each of these lengths into a tile, with the lists in order of work class and in entry order."""
+    if R.path_name != "tiled":
+        pytest.skip("the direct path has no tile lists")
+    R.set_option("tile_rows", 32)
+    try:
+        for per_tile in (6, 20, 100, 150, 200, 300, 600, 3000):
+            sc = pkg.scenes.random_scene(4 * per_tile, 128, 64, seed=0xBEE0 + per_tile, mesh_grid=(128, 64))
+            for classes in (1, 0):
+                R.set_option("work_classes", classes)
+                _check(pkg, oracle, R, sc, label="%d triangles per tile, work classes %d" % (per_tile, classes))
+    finally:
+        R.set_option("work_classes", 1)
+        R.set_option("tile_rows", 0)
 
 
 def test_spinning_cube_and_other_model_matrices(pkg, oracle, R, golden_dir):
