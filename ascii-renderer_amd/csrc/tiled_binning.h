@@ -24,13 +24,14 @@ namespace {
 //             place, two levels) and per-row-block bin totals: every (workgroup, bin) pair gets a
 //             fixed slice of the bin's entry array without a single global atomic.
 //   k_fill    bin totals -> start of every bin's entry array (each workgroup scans them for itself), then
-//             every k_setup workgroup's survivors become one entry (id, mask of the bin's tiles the
-//             cell range touches) per (survivor, bin), written into that workgroup's slice.
-//   k_tile    one workgroup per tile: filters its bin's entries by mask bit into an LDS work list,
-//             fetches the listed triangles' records, redoes their setup (same expressions as k_setup,
-//             hence the same values) and rasterises them into a 2048-entry LDS key tile with LDS
-//             atomic min (small cell ranges: one lane per triangle; large ones: staged in LDS, one
-//             wavefront sweeps each), then shades the covered cells and writes the tile's RGBA /
+//             every k_setup workgroup's survivors become one entry (id, work class, mask of the bin's
+//             tiles the cell range touches) per (survivor, bin), written into that workgroup's slice.
+//   k_tile    one workgroup per tile: filters its bin's entries by mask bit into an LDS work list kept in
+//             order of work class, fetches the listed triangles' records, redoes their setup (same
+//             expressions as k_setup, hence the same values) and rasterises them into an LDS key tile
+//             (64 x 32, 16 or 8 cells) with LDS atomic min (small cell ranges: one lane - or a few -
+//             per triangle; large ones: staged in LDS, one wavefront sweeps each), then shades the
+//             covered cells and writes the tile's RGBA /
 //             depth / ramp-index rows.  Visibility keys never touch HBM, and no per-frame setup
 //             result does either: a scattered 64-byte read costs the memory side a whole request
 //             whether it fetches a setup record or the static triangle, and the static triangle
