@@ -124,6 +124,14 @@ def main():
             R.set_mesh(c["vbo"], c["idx"])
         R.set_mesh_uv(c["uv8"]); R.set_texture(c["atlas"])
         R.set_camera(c["proj"], c["view"]); R.set_lights(c["lights"])
+        # every third case puts the mesh under a model matrix: turned, scaled, moved a little (its own generator, so that
+        # the other parameters of a case do not depend on it)
+        model = None
+        if n % 3 == 1:
+            mrng = np.random.default_rng(1000003 * n + 17)
+            model = ar.geometry.spin_matrix(float(mrng.uniform(-3.0, 3.0)), axis=tuple(mrng.normal(size=3) + 1e-3),
+                                            translate=tuple(mrng.uniform(-0.3, 0.3, size=3)), scale=float(mrng.uniform(0.6, 1.6)))
+        R.set_model(model)
         R.set_ascii(c["ramp"], *c["mode"])
         rows = c["rows"]
         strip = (0, 0)
@@ -134,7 +142,7 @@ def main():
         for _ in range(reps - 1):
             R.render_async(c["cols"], rows)
         out = R.render(c["cols"], rows, want_ids=True)
-        rgba, depth, ids = orc.render(c["vbo"], c["idx"], c["proj"], c["view"], c["lights"], c["cols"], rows, uv8=c["uv8"], atlas=c["atlas"])
+        rgba, depth, ids = orc.render(c["vbo"], c["idx"], c["proj"], c["view"], c["lights"], c["cols"], rows, uv8=c["uv8"], atlas=c["atlas"], model=model)
         asc = orc.quantize(rgba, c["cols"], rows, c["ramp"], int(c["mode"][0]), c["mode"][1], c["mode"][2])
         r0, r1 = strip if strip[1] > strip[0] else (0, rows)
         h0, h1 = max(0, r0 - 3), min(rows, r1 + 3)      # rows a strip renders at least (with smoothing halo)
