@@ -800,6 +800,10 @@ int ar_set_option(ar_ctx *ctx, int option, long long value) {
             if (value != 0 && value != 8 && value != 16 && value != 32) return fail(ctx, AR_E_ARG, "AR_OPT_TILE_ROWS takes 0, 8, 16 or 32");
             ctx->tile_shift_option = value == 8 ? 3 : value == 16 ? 4 : value == 32 ? 5 : 0;
             return 0;
+        case AR_OPT_FOLD_SCAN:
+            if (value != 0 && value != 1) return fail(ctx, AR_E_ARG, "AR_OPT_FOLD_SCAN takes 0 or 1");
+            ctx->no_fold = value == 0;
+            return 0;
         case AR_OPT_WORK_CLASSES:
             if (value != 0 && value != 1) return fail(ctx, AR_E_ARG, "AR_OPT_WORK_CLASSES takes 0 or 1");
             ctx->no_classes = value == 0;

@@ -47,6 +47,8 @@ struct ar_ctx {
     uint32_t pool_cap_option = 0;    // 0: sized from the triangle count
     int tile_shift_option = 0;       // 0: tile height chosen per frame; 3, 4, 5: fixed at 8, 16, 32 rows
     bool no_classes = false;         // AR_OPT_WORK_CLASSES 0: tile lists stay in entry order
+    bool no_fold = false;            // AR_OPT_FOLD_SCAN 0: k_binscan in every frame
+    bool blocksum_zero[kSets] = {};  // the totals behind the count table of a set are zero (left so by a frame without k_binscan)
     float *d_tripos = nullptr;       // 9 planes x tripos_stride floats: triangle positions
     size_t tripos_stride = 0;
     float *d_triattr = nullptr;      // n_tris x 24 floats: the three vertices' normals and colours
@@ -352,7 +354,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
         if (!ctx->d_dircount[0] || ctx->dircount_cap < want_dir) {
             rc = sync_streams(ctx);
             if (rc) return rc;
-            for (int k = 0; k < kSets; k++) { (void)hipFree(ctx->d_dircount[k]); ctx->d_dircount[k] = nullptr; }
+            for (int k = 0; k < kSets; k++) { (void)hipFree(ctx->d_dircount[k]); ctx->d_dircount[k] = nullptr; ctx->blocksum_zero[k] = false; }
             ctx->dircount_cap = 0;
             for (int k = 0; k < kSets; k++) AR_HIP(ctx, hipMalloc(&ctx->d_dircount[k], (want_dir + 16 * size_t(kMaxBins)) * sizeof(uint32_t)));
             ctx->dircount_cap = want_dir;
@@ -360,6 +362,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
     }
     const bool was_clean = ctx->vis_clean;
     ctx->vis_clean = false;  // stays false if anything below fails: the next frame then starts from scratch
+    if (!was_clean) for (int k = 0; k < kSets; k++) ctx->blocksum_zero[k] = false;
     if (!was_clean) {
         // first frame on these targets (or after a failed one).  In steady state every kernel that
         // consumes a visibility key or a queue counter puts it back to its idle value, so no per-frame
@@ -377,12 +380,19 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
     if (tiled) {
         uint32_t *dircount = ctx->d_dircount[set];
         uint32_t *blocksum = dircount + ctx->dircount_cap;
+        // Frames with few bins (small grids, strips of a frame) do without k_binscan: one launch and one gap between
+        // dependent kernels less, which is most of what such a frame costs.  They need the totals behind the count
+        // table at zero; a frame of the other kind (or a failed one) leaves them otherwise.
+        fp.fold_scan = (nbins <= size_t(kFoldScanBins) && !ctx->no_fold) ? 1 : 0;
+        if (fp.fold_scan && !ctx->blocksum_zero[set])
+            AR_HIP(ctx, hipMemsetAsync(blocksum, 0, 16 * size_t(kMaxBins) * sizeof(uint32_t), fs));
+        ctx->blocksum_zero[set] = fp.fold_scan != 0;
         {
             Stamper s(ctx, K_SETUP, fs);
             k_setup<<<fp.n_groups, kSetupThreads, nbins * sizeof(uint32_t), fs>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_box, ctx->d_surv[set], ctx->d_sid[set],
-                                                         ctx->d_surv_count[set], dircount);
+                                                         ctx->d_surv_count[set], dircount, blocksum);
         }
-        {
+        if (!fp.fold_scan) {
             Stamper s(ctx, K_BINSCAN, fs);
             k_binscan<<<dim3(unsigned((nbins + 63) / 64), 16), 64 * kScanWaves, 0, fs>>>(fp, dircount, blocksum);
         }
@@ -398,7 +408,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
                           : fp.tshift == 4 ? (textured ? k_tile<true, 4> : k_tile<false, 4>)
                                            : (textured ? k_tile<true, 3> : k_tile<false, 3>);
             kernel<<<grid, kTileThreads, 0, fs>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_triuv,
-                                         ctx->d_atlas, ctx->d_tri, ctx->d_tri_t, ctx->d_entries[set], ctx->pool_cap, ctx->d_state,
+                                         ctx->d_atlas, ctx->d_tri, ctx->d_tri_t, ctx->d_entries[set], ctx->pool_cap, ctx->d_state, blocksum,
                                          ctx->d_vis[set], ctx->d_rgba[oset], ctx->d_depth[oset], ascii_out, ctx->d_ridx[set],
                                          ctx->d_ids[oset]);
         }

@@ -37,6 +37,8 @@ struct FrameParams {
     int tshift;      // log2 of the tile height in rows (5, 4 or 3)
     int id_bits;     // bits of a bin entry that hold 2*slot + sub (enough for the mesh) ...
     int cls_bits;    // ... and, above them, so many bits of work class (0..6; what is left below the tile mask)
+    int fold_scan;   // 1: no k_binscan in this frame - k_setup adds up the totals per bin and row block, k_fill sums the
+                     // table rows before its own (frames with few bins, where that is cheaper than a kernel)
     uint32_t chunk, n_groups;  // triangles per k_setup workgroup, number of those workgroups
     uint32_t frame;  // frame counter
     int set;         // buffer set of this frame (frame % kSets): binning state block, survivor slots, ...

@@ -430,7 +430,7 @@ __device__ __forceinline__ bool sub_triangle_screen(const FrameParams &fp, const
 __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const float *__restrict__ tripos, size_t stride,
                                                          const float *__restrict__ box, uint2 *__restrict__ surv,
                                                          uint32_t *__restrict__ sid, uint32_t *__restrict__ surv_count,
-                                                         uint32_t *__restrict__ dircount) {
+                                                         uint32_t *__restrict__ dircount, uint32_t *__restrict__ blocksum) {
     // (LDS sized by the launch to the frame's bins, not to the most a frame can have: the frame's kernels run beside
     // the tile resolve of the frame before, which leaves them a fifth of a compute unit's LDS)
     extern __shared__ uint32_t bins_lds[];
@@ -509,7 +509,15 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const f
         }
     }
     __syncthreads();
-    for (int k = int(tid); k < nbins; k += kSetupThreads) dircount[size_t(blockIdx.x) * nbins + k] = hist[k];
+    // The workgroup's row of the count table.  In a frame without k_binscan (fp.fold_scan) also its share of the totals
+    // per bin and row block (16 row blocks of consecutive workgroups; blocksum is zero when such a frame starts): with
+    // the triangles in spatial order a workgroup touches a handful of bins, so these are few atomics.
+    const uint32_t my_block = blockIdx.x / ((fp.n_groups + 15u) / 16u);
+    for (int k = int(tid); k < nbins; k += kSetupThreads) {
+        const uint32_t h = hist[k];
+        dircount[size_t(blockIdx.x) * nbins + k] = h;
+        if (fp.fold_scan && h != 0u) atomicAdd(&blocksum[size_t(my_block) * nbins + k], h);
+    }
     if (tid == 0) surv_count[blockIdx.x] = run;
 }
 
@@ -523,6 +531,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const f
 // before, which leaves room for one or two wavefronts per SIMD - a workgroup that needs four of them on one
 // compute unit waits until tiles there have finished (measured: 20 us, for every third frame).
 constexpr int kScanWaves = 4;
+constexpr int kFoldScanBins = 160;  // frames with at most so many bins go without k_binscan (FrameParams::fold_scan)
 static_assert(kMaxGroups <= 16u * 16u * kScanWaves, "a wavefront of k_binscan takes at most 16 rows of its row block");
 __global__ __launch_bounds__(64 * kScanWaves) void k_binscan(FrameParams fp, uint32_t *__restrict__ table, uint32_t *__restrict__ blocksum) {
     __shared__ uint32_t part[kScanWaves][64];
@@ -588,8 +597,21 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Tr
             total += x;
             before += y < my_block ? x : 0u;
         }
+        if (fp.fold_scan) {
+            // no k_binscan has run: the table holds plain counts, and the entries of the earlier workgroups of this
+            // row block are the sum of their rows (up to 63 rows of bins words from L2, sixteen loads in flight)
+            for (uint32_t g0 = my_block * rows_per_block; g0 < blockIdx.x; g0 += 16u) {
+                uint32_t x[16];
+#pragma unroll
+                for (uint32_t k = 0; k < 16; k++) x[k] = g0 + k < blockIdx.x ? dircount[size_t(g0 + k) * nbins + b] : 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < 16; k++) before += x[k];
+            }
+        } else {
+            before += dircount[size_t(blockIdx.x) * nbins + b];  // (scanned by k_binscan)
+        }
         cnt[b] = total;
-        base[b] = before + dircount[size_t(blockIdx.x) * nbins + b];
+        base[b] = before;
     }
     __syncthreads();
     // exclusive scan of the totals over the bins: each lane takes a run of consecutive bins (one bin per lane up

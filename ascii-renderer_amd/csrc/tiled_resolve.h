@@ -287,7 +287,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const flo
                                               const uint4 *__restrict__ triuv, const uint32_t *__restrict__ atlas,
                                               const TriStatic *__restrict__ tri, const TriStatic *__restrict__ tri_t,
                                               const uint32_t *__restrict__ entries, uint32_t entries_cap,
-                                              const BinState *__restrict__ state, uint64_t *__restrict__ vis,
+                                              const BinState *__restrict__ state, uint32_t *__restrict__ blocksum,
+                                              uint64_t *__restrict__ vis,
                                               uint8_t *__restrict__ rgba, float *__restrict__ depth,
                                               uint8_t *__restrict__ ascii, uint8_t *__restrict__ ridx,
                                               uint32_t *__restrict__ ids) {
@@ -303,6 +304,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const flo
     // Workgroups are handed to the eight XCDs round-robin and each XCD has its own L2: the tiles of one
     // bin, which all read the bin's entry array, are given workgroup numbers that are equal modulo 8.
     // Workgroup B = 8 * tiles_per_bin * g + 8 * k + x is tile k of bin 8 g + x.
+    // (a frame without k_binscan: k_fill has used the totals per bin and row block that k_setup added up - they go
+    // back to zero for the next such frame on this set of buffers)
+    if (fp.fold_scan && blockIdx.x == 0)
+        for (int k = int(threadIdx.x); k < 16 * fp.nbx * fp.nby; k += kTileThreads) blocksum[k] = 0;
     const int side = 1 << fp.bshift, tiles_per_bin = side * side;
     const int wg_group = int(blockIdx.x) / (8 * tiles_per_bin), wg_in = int(blockIdx.x) % (8 * tiles_per_bin);
     const int bin = wg_group * 8 + (wg_in & 7), sub = wg_in >> 3;

@@ -268,12 +268,15 @@ int ar_frame_counters(ar_ctx *ctx, uint32_t out[8]);
  *                        (a strip, a small grid) would otherwise have fewer than 512 tiles; 8, 16, 32 fix it.
  *   AR_OPT_WORK_CLASSES  1 (default): every tile orders its list of triangles by a work class (rows and width of the
  *                        cell range, carried in spare bits of the bin entries) so that the lanes of a wavefront get
- *                        triangles of one kind; 0: lists stay in entry order.  Same frames either way. */
+ *                        triangles of one kind; 0: lists stay in entry order.  Same frames either way.
+ *   AR_OPT_FOLD_SCAN     1 (default): frames with at most 160 bins (small grids, strips) run without the scan kernel of
+ *                        the binning step, its work folded into the kernels before and after it; 0: never. */
 #define AR_OPT_PATH 1
 #define AR_OPT_POOL_RECORDS 2
 #define AR_OPT_OVERLAP 3
 #define AR_OPT_TILE_ROWS 4
 #define AR_OPT_WORK_CLASSES 5
+#define AR_OPT_FOLD_SCAN 6
 int ar_set_option(ar_ctx *ctx, int option, long long value);
 
 #ifdef __cplusplus

@@ -118,6 +118,7 @@ def main():
         R.set_option("path", c["path"]); R.set_option("pool_records", c["pool"]); R.set_option("overlap", min(c["overlap"], 1))
         R.set_option("tile_rows", (0, 8, 16, 32, 0)[n % 5])      # the tile height: chosen by the library, or each fixed one
         R.set_option("work_classes", 0 if n % 7 == 3 else 1)      # tile lists in entry order now and then
+        R.set_option("fold_scan", 0 if n % 4 == 2 else 1)         # the scan kernel also where the frame would do without
         if c["indexed"] is not None:
             R.set_mesh_indexed(*c["indexed"])
         else:

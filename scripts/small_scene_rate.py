@@ -14,6 +14,8 @@ proj, view = ar.host.camera_matrices({"pos": (0.0, 1.5, 6.0), "yaw": -1.2, "pitc
 cases = [("default scene (768 tris) 96x36", {"vbo": vbo, "idx": idx, "proj": proj, "view": view, "lights": ar.host.pack_lights(scene), "cols": 96, "rows": 36}),
          ("cube (12 tris) 80x40", ar.scenes.cube_scene()), ("icosphere (5120 tris) 640x360", ar.scenes.icosphere_scene())]
 R = ar.Renderer(0)
+if os.environ.get("AR_FOLD_SCAN"):
+    R.set_option("fold_scan", int(os.environ["AR_FOLD_SCAN"]))
 for name, sc in cases:
     ar.scenes.upload(R, sc)
     cols, rows = sc["cols"], sc["rows"]

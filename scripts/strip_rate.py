@@ -14,6 +14,8 @@ sc = (ar.scenes.random_scene(10_000_000, cols, rows, seed=0xA5C12, point_lights=
       else ar.scenes.random_scene(1_000_000, cols, rows))
 print("config %s: %d triangles, %dx%d" % (config, sc["idx"].size // 3, cols, rows), flush=True)
 R = ar.Renderer(0)
+if os.environ.get("AR_FOLD_SCAN"):
+    R.set_option("fold_scan", int(os.environ["AR_FOLD_SCAN"]))
 ar.scenes.upload(R, sc)
 for world in (1, 2, 4, 8):
     worst = None
