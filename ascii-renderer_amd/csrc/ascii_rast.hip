@@ -1,10 +1,11 @@
 // ascii_rast.hip - MI355X (gfx950) 3D -> ASCII rasterizer: HIP kernels and the C ABI around them.
 //
 // Two resolve paths produce identical frames (nothing leaves HBM between their stages):
-//   tiled (default)   k_setup -> k_binscan -> k_fill -> k_tile -> k_ascii_plane
+//   tiled (default)   k_setup -> k_binscan -> k_fill -> k_tile -> smoothing (k_ascii_counts for ramps of at most ten
+//                     glyphs and radius <= 2, else k_ascii_plane; k_ascii when the frame carries ASCII overrides)
 //                     triangles are culled and binned to screen bins, then resolved per 64x32-cell
 //                     tile in LDS; described in front of k_tristream.
-//   direct            k_raster -> k_raster_medium -> k_raster_large -> k_shade -> k_ascii_plane
+//   direct            k_raster -> k_raster_medium -> k_raster_large -> k_shade -> smoothing (as above)
 //                     k_raster: one lane per triangle (vertex transform, near clip, edge setup, cull,
 //                     cell range); small triangles are scanned in place, larger ones queued as setup
 //                     records for k_raster_medium (one wavefront per record, 8x8 cells per step) and
@@ -44,8 +45,9 @@
 // ---- ar_quantize without allocations ------------------------------------------------------------------------
 // ar_quantize stages the caller's RGBA grid and the ASCII plane in device memory that it allocates (and grows) on
 // demand.  The variant below stages them in a fixed array that is part of the loaded code object instead, so that
-// it never calls hipMalloc / hipFree: for callers that cannot allocate (under HIP graph capture, in serving loops
-// and harnesses that forbid it).  Every GPU the library runs on holds its own copy of the array until the process
+// it never calls hipMalloc / hipFree: for callers that cannot allocate (serving loops and harnesses that forbid it, code
+// that runs while another thread captures a HIP graph; the call itself copies from and to pageable host memory and
+// waits for its stream, so it is not itself capturable).  Every GPU the library runs on holds its own copy of the array until the process
 // ends; all calls on a GPU share it, so calls that overlap on one GPU race, and it keeps the last call's contents
 // (nothing in it has to start at zero: a call overwrites every byte it later reads).
 static __device__ __align__(256) unsigned char scratch[size_t(AR_STATIC_MAX_CELLS) * 5];  // RGBA staging, then the ASCII plane
@@ -99,13 +101,11 @@ ar_ctx *ar_create(int device_id) {
         ar_destroy(ctx);
         return nullptr;
     }
-    {   // this device's copy of the static staging array (ar_quantize_static): its address is looked up here, once per device
+    {   // this device's copy of the static staging array (ar_quantize_static): its address is looked up here, once per
+        // device; a failure is that entry point's to report (it looks again), never the context's
         unsigned char *p = nullptr;
-        if (static_scratch(ctx, &p) != 0) {
-            fail(nullptr, AR_E_HIP, "context setup failed: %s", ctx->err);
-            ar_destroy(ctx);
-            return nullptr;
-        }
+        (void)static_scratch(ctx, &p);
+        ctx->err[0] = '\0';
     }
     memset(&ctx->fp, 0, sizeof ctx->fp);
     static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
@@ -381,8 +381,7 @@ int ar_set_stream(ar_ctx *ctx, void *hip_stream) {
 int ar_set_ascii_target(ar_ctx *ctx, void *d_ascii, int first_row) {
     if (!ctx) return AR_E_ARG;
     if (first_row < 0) return fail(ctx, AR_E_ARG, "ar_set_ascii_target: bad first row %d", first_row);
-    // the smoothing kernel stores four codes at a time when the row length is a multiple of four
-    if (reinterpret_cast<uintptr_t>(d_ascii) & 3u) return fail(ctx, AR_E_ARG, "ar_set_ascii_target: the buffer must be 4-byte aligned");
+    // (alignment is checked per frame, where the row length is known: see ascii_target_misaligned)
     ctx->ascii_target = static_cast<uint8_t *>(d_ascii);
     ctx->target_row = d_ascii ? first_row : 0;
     return 0;
@@ -461,7 +460,7 @@ int ar_quantize_static(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uin
                     cols, rows, n, AR_STATIC_MAX_CELLS);
     AR_HIP(ctx, hipSetDevice(ctx->device));
     unsigned char *base = nullptr;
-    int rc = static_scratch(ctx, &base);  // (looked up at ar_create; this is the fallback for a context whose creation could not)
+    int rc = static_scratch(ctx, &base);  // (normally found at ar_create; looked up again here if that failed, and reported here)
     if (rc) return rc;
     uint8_t *d_rgba = base, *d_ascii = base + size_t(AR_STATIC_MAX_CELLS) * 4;
     FrameParams fp = ctx->fp;
@@ -527,6 +526,8 @@ int ar_rt_render_async(ar_ctx *ctx, int cols, int rows, const float cam_pos[3], 
     if (!ctx) return AR_E_ARG;
     if (!cam_pos || cols <= 0 || rows <= 0 || size_t(cols) * rows > (size_t(1) << 31))
         return fail(ctx, AR_E_ARG, "ar_rt_render: bad arguments (%d x %d)", cols, rows);
+    if (ascii_target_misaligned(ctx, cols))
+        return fail(ctx, AR_E_ARG, "ar_rt_render: the ASCII target must be 4-byte aligned when the row length (%d) is a multiple of four", cols);
     AR_HIP(ctx, hipSetDevice(ctx->device));
     int rc = ensure_targets(ctx, cols, rows);
     if (rc) return rc;

@@ -242,6 +242,12 @@ int finish_mesh(ar_ctx *ctx, uint32_t n_verts, uint32_t n_tris) {
     return 0;
 }
 
+// The smoothing kernels store four codes at a time when the row length is a multiple of four, and bytes otherwise: a
+// caller's ASCII target has to be 4-byte aligned in the first case only (row starts then are as well).
+bool ascii_target_misaligned(const ar_ctx *ctx, int cols) {
+    return ctx->ascii_target && (cols & 3) == 0 && (reinterpret_cast<uintptr_t>(ctx->ascii_target) & 3u) != 0;
+}
+
 // Frames whose caller does not wait for them right away (may_overlap) run entirely on one of kSets frame
 // streams, frame f on stream f % kSets, and every buffer a frame writes exists kSets times: consecutive
 // frames share the GPU without a single cross-stream event (each of which costs the host about as much as
@@ -250,6 +256,8 @@ int finish_mesh(ar_ctx *ctx, uint32_t n_verts, uint32_t n_tris) {
 int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
     if (cols <= 0 || rows <= 0 || size_t(cols) * rows > (size_t(1) << 31))
         return fail(ctx, AR_E_ARG, "ar_render: bad grid %d x %d", cols, rows);
+    if (ascii_target_misaligned(ctx, cols))
+        return fail(ctx, AR_E_ARG, "ar_render: the ASCII target must be 4-byte aligned when the row length (%d) is a multiple of four", cols);
     AR_HIP(ctx, hipSetDevice(ctx->device));
     int rc = ensure_targets(ctx, cols, rows);
     if (rc) return rc;

@@ -303,8 +303,10 @@ napi_value js_render(napi_env env, napi_callback_info info) {
     return out;
 }
 
-// rtSetScene(handle, {numS, S4, Si, numP, P4, Pi, numT, Ta, Tb, Tc, Ti, numMats, Ma, Mr, numPL, Ppos, Pcol, numDL, Ddir, Dcol, envCol}):
-// the packed uniform arrays of the ray backend (field names as RaytraceBackend._cache, raytrace.js:303-311)
+// rtSetScene(handle, packed): the ray backend's scene arrays as packRaytraceScene (js/hip_raytrace_backend.js) lays them
+// out - sphereCount / sphereGeom / sphereMaterial, planeCount / planeGeom / planeMaterial, triCount / triA / triB / triC /
+// triMaterial, materialCount / materialAlbedo / materialMirror, pointCount / pointPos / pointColor, dirCount / dirDir /
+// dirColor, environment - i.e. the uniform arrays of raytrace.js:349-389
 napi_value js_rt_set_scene(napi_env env, napi_callback_info info) {
     napi_value argv[2];
     if (!get_args(env, info, 2, argv)) return nullptr;
@@ -328,27 +330,27 @@ napi_value js_rt_set_scene(napi_env env, napi_callback_info info) {
         if (len < need) { ok = false; napi_throw_range_error(env, nullptr, "rtSetScene: array shorter than its count"); return nullptr; }
         return need ? data : nullptr;
     };
-    sc.n_spheres = count("numS"); sc.n_planes = count("numP"); sc.n_tris = count("numT");
-    sc.n_mats = count("numMats"); sc.n_pl = count("numPL"); sc.n_dl = count("numDL");
+    sc.n_spheres = count("sphereCount"); sc.n_planes = count("planeCount"); sc.n_tris = count("triCount");
+    sc.n_mats = count("materialCount"); sc.n_pl = count("pointCount"); sc.n_dl = count("dirCount");
     if (!ok || sc.n_spheres < 0 || sc.n_planes < 0 || sc.n_tris < 0 || sc.n_mats < 0 || sc.n_pl < 0 || sc.n_dl < 0) {
         napi_throw_type_error(env, nullptr, "rtSetScene: counts missing or negative");
         return nullptr;
     }
-    sc.spheres4 = static_cast<const float *>(array("S4", napi_float32_array, size_t(sc.n_spheres) * 4));
-    sc.sphere_mat = static_cast<const int32_t *>(array("Si", napi_int32_array, size_t(sc.n_spheres)));
-    sc.planes4 = static_cast<const float *>(array("P4", napi_float32_array, size_t(sc.n_planes) * 4));
-    sc.plane_mat = static_cast<const int32_t *>(array("Pi", napi_int32_array, size_t(sc.n_planes)));
-    sc.tri_a = static_cast<const float *>(array("Ta", napi_float32_array, size_t(sc.n_tris) * 3));
-    sc.tri_b = static_cast<const float *>(array("Tb", napi_float32_array, size_t(sc.n_tris) * 3));
-    sc.tri_c = static_cast<const float *>(array("Tc", napi_float32_array, size_t(sc.n_tris) * 3));
-    sc.tri_mat = static_cast<const int32_t *>(array("Ti", napi_int32_array, size_t(sc.n_tris)));
-    sc.mat_albedo = static_cast<const float *>(array("Ma", napi_float32_array, size_t(sc.n_mats) * 3));
-    sc.mat_reflective = static_cast<const int32_t *>(array("Mr", napi_int32_array, size_t(sc.n_mats)));
-    sc.pl_pos = static_cast<const float *>(array("Ppos", napi_float32_array, size_t(sc.n_pl) * 3));
-    sc.pl_col = static_cast<const float *>(array("Pcol", napi_float32_array, size_t(sc.n_pl) * 3));
-    sc.dl_dir = static_cast<const float *>(array("Ddir", napi_float32_array, size_t(sc.n_dl) * 3));
-    sc.dl_col = static_cast<const float *>(array("Dcol", napi_float32_array, size_t(sc.n_dl) * 3));
-    const float *env3 = static_cast<const float *>(array("envCol", napi_float32_array, 3));
+    sc.spheres4 = static_cast<const float *>(array("sphereGeom", napi_float32_array, size_t(sc.n_spheres) * 4));
+    sc.sphere_mat = static_cast<const int32_t *>(array("sphereMaterial", napi_int32_array, size_t(sc.n_spheres)));
+    sc.planes4 = static_cast<const float *>(array("planeGeom", napi_float32_array, size_t(sc.n_planes) * 4));
+    sc.plane_mat = static_cast<const int32_t *>(array("planeMaterial", napi_int32_array, size_t(sc.n_planes)));
+    sc.tri_a = static_cast<const float *>(array("triA", napi_float32_array, size_t(sc.n_tris) * 3));
+    sc.tri_b = static_cast<const float *>(array("triB", napi_float32_array, size_t(sc.n_tris) * 3));
+    sc.tri_c = static_cast<const float *>(array("triC", napi_float32_array, size_t(sc.n_tris) * 3));
+    sc.tri_mat = static_cast<const int32_t *>(array("triMaterial", napi_int32_array, size_t(sc.n_tris)));
+    sc.mat_albedo = static_cast<const float *>(array("materialAlbedo", napi_float32_array, size_t(sc.n_mats) * 3));
+    sc.mat_reflective = static_cast<const int32_t *>(array("materialMirror", napi_int32_array, size_t(sc.n_mats)));
+    sc.pl_pos = static_cast<const float *>(array("pointPos", napi_float32_array, size_t(sc.n_pl) * 3));
+    sc.pl_col = static_cast<const float *>(array("pointColor", napi_float32_array, size_t(sc.n_pl) * 3));
+    sc.dl_dir = static_cast<const float *>(array("dirDir", napi_float32_array, size_t(sc.n_dl) * 3));
+    sc.dl_col = static_cast<const float *>(array("dirColor", napi_float32_array, size_t(sc.n_dl) * 3));
+    const float *env3 = static_cast<const float *>(array("environment", napi_float32_array, 3));
     if (!ok || !env3) {
         bool pending = false;
         napi_is_exception_pending(env, &pending);

@@ -390,17 +390,20 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const flo
                     my_part += 1u << gshift;
                 }
             }
+            // A list word may carry kListSweep by the time it is read here: with spare groups two lane groups - usually in
+            // different wavefronts - work on the same entry, and part 0 marks it below without a barrier in between.  Every
+            // read in this loop therefore masks the mark off (with it the word would index 2^30 records past the array).
             TriStatic ahead;
-            if (first < nl) ahead = tri[list[first] >> 1];  // (the first run of 256 is in order)
+            if (first < nl) ahead = tri[(list[first] & ~kListSweep) >> 1];  // (the first run of 256 is in order)
             // (list place and the lane's number among the lanes of its entry travel in one register: they are few bits each,
             // and registers are what limits this kernel)
             for (uint32_t rp = first | (my_part << 16); (rp & 0xFFFFu) < n_rounds * per_round; rp += per_round) {
                 const uint32_t r = rp & 0xFFFFu;
                 const int part = int(rp >> 16);
                 if (list_slot(r) >= nl) continue;  // (an empty slot: only in the last round)
-                const uint32_t id = list[r];
+                const uint32_t id = list[r] & ~kListSweep;
                 const TriStatic ts = ahead;
-                if (list_slot(r + per_round) < nl) ahead = tri[list[r + per_round] >> 1];
+                if (list_slot(r + per_round) < nl) ahead = tri[(list[r + per_round] & ~kListSweep) >> 1];
                 Screen sc;
                 bool clipped;
                 int ci0, ci1, cj0, cj1;
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const flo
                 const int len = (r1 - r0 + (1 << pshift)) >> pshift;
                 const int w = i1 - i0 + 1;
                 if ((len << (w <= 1 ? 0 : 32 - __clz(w - 1))) > kTileSmallCells) {
-                    if (part == 0) { list[r] = id | kListSweep; n_marked = 1u; }  // (its own entry: nobody else reads or writes it in this loop)
+                    if (part == 0) { list[r] = id | kListSweep; n_marked = 1u; }  // (the only writer of this word; readers mask the mark off)
                     continue;
                 }
                 r0 += part * len;  // this lane's share of the rows

@@ -2,12 +2,13 @@
 //
 // API surface of the reference's AsciiPass (js/ascii_pass.js:130-344): constructor(canvas?, opts),
 // setGridSize, blit, draw, drawFromBuffer, setCellSize, and the atlas descriptor of buildAtlas
-// ({tileW, tileH, tilesPerRow, count, pad, rows}, ascii_pass.js:20-86).  What it computes is the
-// index half of the reference's fragment shader (js/ascii_pass_shader.js:140-188): alpha 2..254 is a
-// literal code, otherwise ramp quantisation with optional modal smoothing, then ramp index -> ASCII
-// code.  Compositing glyph pixels onto a canvas (the shader's lines 190-230) needs a font rasterizer
-// and a display and is outside this path: the result is `codes`, one byte per cell, where the
-// reference would look up tile (code % 16, floor(code / 16)).
+// ({tileW, tileH, tilesPerRow, count, pad, rows}, ascii_pass.js:20-86).  draw() computes the index half of the
+// reference's fragment shader (js/ascii_pass_shader.js:140-188): alpha 2..254 is a literal code, otherwise ramp
+// quantisation with optional modal smoothing, then ramp index -> ASCII code; the result is `codes`, one byte per
+// cell, where the reference would look up tile (code % 16, floor(code / 16)).  present() runs the shader's other half
+// as well (lines 190-230: glyph texels composited onto a canvas-sized RGBA image) with an atlas the caller supplies -
+// baking one needs a font rasterizer, which is the only part left out.  colorsFromBuffer() gives the text colours of
+// the reference's DOM presentation.
 import { config } from './config.js';
 import { native } from './native.js';
 import { rampBytes } from './hip_backend.js';

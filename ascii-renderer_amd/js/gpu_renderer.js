@@ -1,96 +1,107 @@
-// gpu_renderer.js - backend plugin registry and the stable render facade.
+// gpu_renderer.js - the backend plugin boundary: a table of named backend factories and the facade the
+// application renders through.
 //
-// Same exports and semantics as the reference's router (js/gpu_renderer.js:52-111):
-//   registerBackend(name, factory)  name lower-cased; throws on bad arguments
-//   listBackends() / getBackend() / setBackend(name)   setBackend disposes the previous backend
-//       (errors swallowed), calls factory() with no arguments and replays the last scene
-//   setScene(scene) / renderScene(timeSec, framebuffer, appState) / renderRaw(args) /
-//   getPixels(args) / disposeGPU()
-// Differences: the built-in registry holds the HIP raster backend ('hip') and the HIP ray backend ('raytrace',
-// aliases 'rt' and 'ray' as in the reference); 'raster' and the reference's aliases for it resolve to 'hip';
-// the default backend is 'hip'; there is no path tracer.
+// Exports and behaviour follow the reference's router contract (js/gpu_renderer.js:52-111):
+//   registerBackend(name, factory)   stored under the lower-cased name; bad arguments throw
+//   listBackends() / getBackend()    names in registration order / name of the live backend
+//   setBackend(name)                 unknown names throw; the old backend's dispose() and the replay of the last
+//                                    scene on the new one may fail without the switch failing; factory() gets no
+//                                    arguments; returns the canonical name
+//   setScene(scene)                  remembered (null for a falsy scene) and handed to the live backend
+//   renderScene(timeSec, framebuffer, appState) / renderRaw(args) / getPixels(args)
+//   disposeGPU()                     drops the live backend; the remembered scene stays
+// Any call that needs a backend while none is live starts the default one first.
+// What differs from the reference: the table starts with the HIP rasterizer ('hip'; 'raster' and the reference's
+// aliases for it lead there, as does 'gpu') and the HIP ray tracer ('raytrace', aliases 'rt' and 'ray'); 'hip' is
+// the default; there is no path tracer.
 import { HipRasterBackend } from './hip_backend.js';
 import { HipRaytraceBackend } from './hip_raytrace_backend.js';
 
-const _registry = new Map([
-  ['hip', () => new HipRasterBackend()],
-  ['raytrace', () => new HipRaytraceBackend()],
-]);
+class BackendRouter {
+  constructor(defaultName) {
+    this.defaultName = defaultName;
+    this.entries = new Map();     // canonical name -> { make, aliases: Set }
+    this.live = null;             // { name, backend } while a backend is up
+    this.scene = null;            // the scene every new backend is brought up with
+  }
 
-const _alias = new Map([
-  ['raster', 'hip'], ['r', 'hip'], ['rasterizer', 'hip'], ['gpu', 'hip'],
-  ['rt', 'raytrace'], ['ray', 'raytrace'],
-]);
+  add(name, make, aliases) {
+    this.entries.set(name, { make, aliases: new Set(aliases || []) });
+    return this;
+  }
 
-let _active = null;
-let _activeName = null;
-let _lastScene = null;
+  // canonical name for a name or alias, or undefined
+  resolve(name) {
+    const wanted = String(name || '').toLowerCase();
+    if (this.entries.has(wanted)) return wanted;
+    for (const [canonical, entry] of this.entries) if (entry.aliases.has(wanted)) return canonical;
+    return undefined;
+  }
 
-function _canonical(name) {
-  const n = String(name || '').toLowerCase();
-  if (_registry.has(n)) return n;
-  const a = _alias.get(n);
-  return _registry.has(a) ? a : null;
+  names() { return [...this.entries.keys()]; }
+
+  // the live backend, starting the default one when there is none
+  backend() {
+    if (!this.live) this.switchTo(this.defaultName);
+    return this.live.backend;
+  }
+
+  // calls backend[method](...args) when the backend has such a method
+  call(backend, method, args, quiet) {
+    if (!backend || typeof backend[method] !== 'function') return undefined;
+    if (!quiet) return backend[method](...args);
+    try { return backend[method](...args); } catch (err) { return undefined; }
+  }
+
+  switchTo(name) {
+    const canonical = this.resolve(name);
+    if (canonical === undefined) throw new Error(`Unknown backend "${name}". Known: ${this.names().join(', ')}`);
+    if (this.live) this.call(this.live.backend, 'dispose', [], true);
+    const backend = this.entries.get(canonical).make();
+    this.live = { name: canonical, backend };
+    if (this.scene) this.call(backend, 'setScene', [this.scene], true);
+    return canonical;
+  }
+
+  shutDown() {
+    if (this.live) this.call(this.live.backend, 'dispose', [], false);
+    this.live = null;
+  }
 }
 
-function _ensureActive() {
-  if (_active) return;
-  setBackend('hip');
-}
+const router = new BackendRouter('hip')
+  .add('hip', () => new HipRasterBackend(), ['raster', 'r', 'rasterizer', 'gpu'])
+  .add('raytrace', () => new HipRaytraceBackend(), ['rt', 'ray']);
 
 export function registerBackend(name, factory) {
-  if (!name || typeof factory !== 'function') {
-    throw new Error('registerBackend(name, factory): invalid args');
-  }
-  _registry.set(String(name).toLowerCase(), factory);
+  if (!name || typeof factory !== 'function') throw new Error('registerBackend(name, factory): invalid args');
+  const key = String(name).toLowerCase(), known = router.entries.get(key);
+  router.add(key, factory, known ? known.aliases : []);   // a replaced backend keeps the aliases that led to it
 }
 
-export function listBackends() {
-  return Array.from(_registry.keys());
-}
+export const listBackends = () => router.names();
 
 export function getBackend() {
-  _ensureActive();
-  return _activeName;
+  router.backend();
+  return router.live.name;
 }
 
-export function setBackend(name) {
-  const key = _canonical(name);
-  if (!key) throw new Error('Unknown backend "' + name + '". Known: ' + listBackends().join(', '));
-  if (_active && _active.dispose) {
-    try { _active.dispose(); } catch (e) { /* as the reference: ignored */ }
-  }
-  _active = _registry.get(key)();
-  _activeName = key;
-  if (_lastScene && _active && _active.setScene) {
-    try { _active.setScene(_lastScene); } catch (e) { /* as the reference: ignored */ }
-  }
-  return _activeName;
-}
+export const setBackend = (name) => router.switchTo(name);
 
 export function setScene(scene) {
-  _lastScene = scene || null;
-  _ensureActive();
-  if (_active && _active.setScene) _active.setScene(_lastScene);
+  router.scene = scene || null;
+  router.call(router.backend(), 'setScene', [router.scene], false);
 }
 
-export function renderScene(timeSec, framebuffer, appState) {
-  _ensureActive();
-  return _active.render(timeSec, framebuffer, appState);
-}
+// (render is the one method every backend must have: called without a check, as the reference does)
+export const renderScene = (timeSec, framebuffer, appState) => router.backend().render(timeSec, framebuffer, appState);
 
-export function renderRaw(args) {
-  _ensureActive();
-  return _active.renderRaw ? _active.renderRaw(args) : undefined;
-}
+export const renderRaw = (args) => router.call(router.backend(), 'renderRaw', [args], false);
 
-export function getPixels(args) {
-  _ensureActive();
-  return _active.getPixels ? _active.getPixels(args) : undefined;
-}
+export const getPixels = (args) => router.call(router.backend(), 'getPixels', [args], false);
 
-export function disposeGPU() {
-  if (_active && _active.dispose) _active.dispose();
-  _active = null;
-  _activeName = null;
-}
+export const disposeGPU = () => router.shutDown();
+
+// Not in the reference: the live backend object, for hosts that use what a backend offers beyond the five-method
+// contract (HipRasterBackend.renderAsync / collect, allocFramebuffer, kernelStats ...).
+export const activeBackend = () => router.backend();

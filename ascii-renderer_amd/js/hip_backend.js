@@ -131,93 +131,142 @@ export function resolveColorTable(scene, prim) {
   return resolveColor(scene, prim.mat, prim.m);
 }
 
-// Scene object -> { vbo: Float32Array(9 * V) (pos, normal, colour), idx: Uint32Array(3 * T) }, the
-// buffers RasterBackend._rebuildGeometry uploads (raster.js:148-257): tris (flat normal), planes
-// (two triangles of half-size 20), spheres (12 x 16 UV mesh); quads are ignored as in the reference.
+// Growing interleaved vertex buffer (position, normal, colour: nine floats per vertex) plus index list: what the scene
+// walkers below emit into.  Values are stored as binary32 on the way in, exactly as a Float32Array built at the end
+// from JavaScript numbers would hold them.
+class MeshAssembler {
+  constructor() {
+    this.floats = new Float32Array(9 * 256);
+    this.indices = new Uint32Array(3 * 256);
+    this.vertexCount = 0;
+    this.indexCount = 0;
+    this.texelRows = [];          // [triangle number, eight u16 values] (textured builds only)
+  }
+
+  get triangleCount() { return this.indexCount / 3; }
+
+  vertex(position, normal, color) {
+    if (9 * (this.vertexCount + 1) > this.floats.length) {
+      const grown = new Float32Array(2 * this.floats.length);
+      grown.set(this.floats);
+      this.floats = grown;
+    }
+    this.floats.set(position, 9 * this.vertexCount);
+    this.floats.set(normal, 9 * this.vertexCount + 3);
+    this.floats.set(color, 9 * this.vertexCount + 6);
+    return this.vertexCount++;
+  }
+
+  triangle(i, j, k) {
+    if (this.indexCount + 3 > this.indices.length) {
+      const grown = new Uint32Array(2 * this.indices.length);
+      grown.set(this.indices);
+      this.indices = grown;
+    }
+    this.indices[this.indexCount++] = i; this.indices[this.indexCount++] = j; this.indices[this.indexCount++] = k;
+  }
+
+  // three unshared vertices carrying the face normal normalize(cross(q - p, r - p)), or (0, 1, 0) for a face of
+  // length <= 1e-8 (raster.js:159-169)
+  flatTriangle(p, q, r, color) {
+    let n = cross([q[0] - p[0], q[1] - p[1], q[2] - p[2]], [r[0] - p[0], r[1] - p[1], r[2] - p[2]]);
+    const len = Math.hypot(n[0], n[1], n[2]);
+    n = len > 1e-8 ? [n[0] / len, n[1] / len, n[2] / len] : [0, 1, 0];
+    this.triangle(this.vertex(p, n, color), this.vertex(q, n, color), this.vertex(r, n, color));
+  }
+
+  texels(row) { this.texelRows.push([this.triangleCount, row]); }   // for the triangle emitted next
+
+  finish(withTexels) {
+    const out = { vbo: this.floats.slice(0, 9 * this.vertexCount), idx: this.indices.slice(0, this.indexCount) };
+    if (withTexels) {
+      out.uv8 = new Uint16Array(this.triangleCount * 8);
+      for (const [t, row] of this.texelRows) out.uv8.set(row, 8 * t);
+    }
+    return out;
+  }
+}
+
+// The four corners of a plane's stand-in rectangle in the order the two triangles use them: signs of the two
+// in-plane axes (raster.js:187-193).
+const PLANE_CORNER_SIGNS = [[-1, -1], [1, -1], [1, 1], [-1, 1]];
+const PLANE_TRIANGLES = [[0, 1, 2], [0, 2, 3]];
+
+function emitPlane(mesh, plane, color) {
+  const unit = normalize(plane.n ? [plane.n[0], plane.n[1], plane.n[2]] : [0, 1, 0]);
+  const offset = Number.isFinite(plane.d) ? plane.d : 0;
+  const foot = [-offset * unit[0], -offset * unit[1], -offset * unit[2]];           // the plane's point nearest the origin
+  const helper = Math.abs(unit[1]) < 0.99 ? [0, 1, 0] : [1, 0, 0];
+  const axisU = normalize(cross(unit, helper)), axisV = normalize(cross(unit, axisU));
+  const corners = PLANE_CORNER_SIGNS.map(([su, sv]) => foot.map((f, k) => f + (su * PLANE_HALF_SIZE * axisU[k] + sv * PLANE_HALF_SIZE * axisV[k])));
+  for (const [i, j, k] of PLANE_TRIANGLES) mesh.flatTriangle(corners[i], corners[j], corners[k], color);
+}
+
+// Latitude / longitude sphere with smooth normals: (SPHERE_LAT + 1) rings of (SPHERE_LON + 1) vertices, ring 0 at
+// the +Y pole, two triangles per cell wound (here, below, right), (right, below, below-right) (raster.js:196-219).
+function emitSphere(mesh, sphere, color) {
+  const centre = sphere.p || [0, 0, 0], radius = Number.isFinite(sphere.r) ? sphere.r : 1;
+  const ring = SPHERE_LON + 1;
+  let first = -1;
+  for (let lat = 0; lat <= SPHERE_LAT; lat++) {
+    const polar = (lat / SPHERE_LAT) * Math.PI, sinPolar = Math.sin(polar), cosPolar = Math.cos(polar);
+    for (let lon = 0; lon <= SPHERE_LON; lon++) {
+      const around = (lon / SPHERE_LON) * 2 * Math.PI;
+      const out = [Math.cos(around) * sinPolar, cosPolar, Math.sin(around) * sinPolar];
+      const v = mesh.vertex([centre[0] + radius * out[0], centre[1] + radius * out[1], centre[2] + radius * out[2]], out, color);
+      if (first < 0) first = v;
+    }
+  }
+  for (let lat = 0; lat < SPHERE_LAT; lat++) {
+    for (let lon = 0; lon < SPHERE_LON; lon++) {
+      const here = first + lat * ring + lon, below = here + ring;
+      mesh.triangle(here, below, here + 1);
+      mesh.triangle(here + 1, below, below + 1);
+    }
+  }
+}
+
+// A quad as the path tracer sees it (pathtrace.js:215-218, shader_utils.js:190-191): halves (a, b, c) and (a, c, d),
+// two-sided - emitted once per winding, of which back-face culling keeps one pair.  Corner numbers per emitted triangle:
+const QUAD_TRIANGLES = [[0, 1, 2], [0, 2, 3], [0, 2, 1], [0, 3, 2]];
+
+function emitQuad(mesh, quad, color) {
+  const corner = [quad.a || [0, 0, 0], quad.b || [1, 0, 0], quad.c || [1, 1, 0], quad.d || [0, 1, 0]];
+  const texel = [uvOf(quad.uv0), uvOf(quad.uv1), uvOf(quad.uv2), uvOf(quad.uv3)];
+  for (const tri of QUAD_TRIANGLES) {
+    // sampleQuadFetch (shader_utils.js:120-132) samples a half unless all three of its coordinate pairs are zero; the
+    // mirrored copy of a half has the same three pairs
+    const sampled = tri.some((c) => texel[c][0] !== 0 || texel[c][1] !== 0) ? 1 : 0;
+    mesh.texels([...texel[tri[0]], ...texel[tri[1]], ...texel[tri[2]], sampled, 0]);
+    mesh.flatTriangle(corner[tri[0]], corner[tri[1]], corner[tri[2]], color);
+  }
+}
+
+// Scene object -> { vbo: Float32Array(9 * V) (position, normal, colour), idx: Uint32Array(3 * T) }, the buffers
+// RasterBackend._rebuildGeometry uploads (raster.js:148-257): tris (flat normal), then planes (two triangles of
+// half-size 20), then spheres (12 x 16 latitude / longitude mesh); quads are ignored as in the reference.
 //
-// opts.textured goes beyond the reference's raster backend (which draws neither quads nor textures) and
-// adds `uv8` to the result: quads are appended after everything else, two-sided as in the path tracer
-// (iTriangle turns the normal towards the viewer, shader_utils.js:54-55) - halves (a,b,c) and (a,c,d)
-// (shader_utils.js:190-191) plus the same two with reversed winding, of which back-face culling keeps
-// one pair; colours resolve through materials.table when the scene has one; uv8 holds one row
-// (u0, v0, u1, v1, u2, v2, flags, 0) per triangle for ar_set_mesh_uv, flags bit 0 set where the path
-// tracer would sample the atlas: every `tris` item (sampleTriFetch), a quad half unless its three
-// coordinate pairs are all zero (sampleQuadFetch, shader_utils.js:108-132).
+// opts.textured goes beyond the reference's raster backend (which draws neither quads nor textures) and adds `uv8`
+// to the result: quads are appended after everything else (emitQuad); colours resolve through materials.table when
+// the scene has one; uv8 holds one row (u0, v0, u1, v1, u2, v2, flags, 0) per triangle for ar_set_mesh_uv, flags bit
+// 0 set where the path tracer would sample the atlas: every `tris` item (sampleTriFetch), a quad half unless its
+// three coordinate pairs are all zero.
 export function buildGeometry(scene, opts) {
   const textured = !!(opts && opts.textured);
   if (!scene) return { vbo: new Float32Array(0), idx: new Uint32Array(0), uv8: textured ? new Uint16Array(0) : undefined };
   if (scene.mesh && scene.mesh.positions && scene.mesh.indices) return meshToVbo(scene.mesh.positions, scene.mesh.indices, scene.mesh.colors);
-  const pos = [], nrm = [], col = [], idx = [];
-  const uvRows = [];                 // [triangle number, row] pairs (textured mode)
-  const colorOf = textured ? (p) => resolveColorTable(scene, p) : (p) => resolveColor(scene, p.mat, p.m);
-  const pushTri = (a, b, c, color) => {
-    const U = [b[0] - a[0], b[1] - a[1], b[2] - a[2]], V = [c[0] - a[0], c[1] - a[1], c[2] - a[2]];
-    let N = cross(U, V);
-    const L = Math.hypot(N[0], N[1], N[2]);
-    N = L > 1e-8 ? [N[0] / L, N[1] / L, N[2] / L] : [0, 1, 0];
-    const base = pos.length / 3;
-    pos.push(a[0], a[1], a[2], b[0], b[1], b[2], c[0], c[1], c[2]);
-    nrm.push(N[0], N[1], N[2], N[0], N[1], N[2], N[0], N[1], N[2]);
-    col.push(color[0], color[1], color[2], color[0], color[1], color[2], color[0], color[1], color[2]);
-    idx.push(base, base + 1, base + 2);
-  };
-  const G = scene.geometry || {};
-  for (const t of (scene.tris || G.tris || [])) {
-    if (textured) uvRows.push([idx.length / 3, [...uvOf(t.uvA), ...uvOf(t.uvB), ...uvOf(t.uvC), 1, 0]]);
-    pushTri(t.a || [0, 0, 0], t.b || [1, 0, 0], t.c || [0, 1, 0], colorOf(t));
+  const colorOf = textured ? (prim) => resolveColorTable(scene, prim) : (prim) => resolveColor(scene, prim.mat, prim.m);
+  const nested = scene.geometry || {};
+  const listOf = (kind) => scene[kind] || nested[kind] || [];
+  const mesh = new MeshAssembler();
+  for (const t of listOf('tris')) {
+    if (textured) mesh.texels([...uvOf(t.uvA), ...uvOf(t.uvB), ...uvOf(t.uvC), 1, 0]);
+    mesh.flatTriangle(t.a || [0, 0, 0], t.b || [1, 0, 0], t.c || [0, 1, 0], colorOf(t));
   }
-  for (const p of (scene.planes || G.planes || [])) {
-    const n = p.n || [0, 1, 0], d = Number.isFinite(p.d) ? p.d : 0, color = colorOf(p);
-    const N = normalize([n[0], n[1], n[2]]);
-    const P0 = [-d * N[0], -d * N[1], -d * N[2]];
-    const tmp = Math.abs(N[1]) < 0.99 ? [0, 1, 0] : [1, 0, 0];
-    const b1 = normalize(cross(N, tmp)), b2 = normalize(cross(N, b1)), S = PLANE_HALF_SIZE;
-    const corner = (s1, s2) => [P0[0] + (s1 * S * b1[0] + s2 * S * b2[0]), P0[1] + (s1 * S * b1[1] + s2 * S * b2[1]), P0[2] + (s1 * S * b1[2] + s2 * S * b2[2])];
-    const v0 = corner(-1, -1), v1 = corner(1, -1), v2 = corner(1, 1), v3 = corner(-1, 1);
-    pushTri(v0, v1, v2, color); pushTri(v0, v2, v3, color);
-  }
-  for (const s of (scene.spheres || G.spheres || [])) {
-    const c = s.p || [0, 0, 0], r = Number.isFinite(s.r) ? s.r : 1, color = colorOf(s);
-    const baseVert = pos.length / 3;
-    for (let iy = 0; iy <= SPHERE_LAT; iy++) {
-      const phi = (iy / SPHERE_LAT) * Math.PI, sp = Math.sin(phi), cp = Math.cos(phi);
-      for (let ix = 0; ix <= SPHERE_LON; ix++) {
-        const th = (ix / SPHERE_LON) * 2 * Math.PI, st = Math.sin(th), ct = Math.cos(th);
-        const nx = ct * sp, ny = cp, nz = st * sp;
-        pos.push(c[0] + r * nx, c[1] + r * ny, c[2] + r * nz);
-        nrm.push(nx, ny, nz);
-        col.push(color[0], color[1], color[2]);
-      }
-    }
-    for (let iy = 0; iy < SPHERE_LAT; iy++) {
-      for (let ix = 0; ix < SPHERE_LON; ix++) {
-        const i0 = baseVert + iy * (SPHERE_LON + 1) + ix, i1 = i0 + 1, i2 = i0 + (SPHERE_LON + 1), i3 = i2 + 1;
-        idx.push(i0, i2, i1, i1, i2, i3);
-      }
-    }
-  }
-  if (textured) {
-    for (const q of (scene.quads || G.quads || [])) {
-      const a = q.a || [0, 0, 0], b = q.b || [1, 0, 0], c = q.c || [1, 1, 0], d = q.d || [0, 1, 0];   // pathtrace.js:215-218
-      const u0 = uvOf(q.uv0), u1 = uvOf(q.uv1), u2 = uvOf(q.uv2), u3 = uvOf(q.uv3), color = colorOf(q);
-      const any = (...u) => (u.some((p) => p[0] !== 0 || p[1] !== 0) ? 1 : 0);
-      const s1 = any(u0, u1, u2), s2 = any(u0, u2, u3);
-      for (const [p0, p1, p2, w0, w1, w2, flag] of [[a, b, c, u0, u1, u2, s1], [a, c, d, u0, u2, u3, s2], [a, c, b, u0, u2, u1, s1], [a, d, c, u0, u3, u2, s2]]) {
-        uvRows.push([idx.length / 3, [...w0, ...w1, ...w2, flag, 0]]);
-        pushTri(p0, p1, p2, color);
-      }
-    }
-  }
-  const V = pos.length / 3, vbo = new Float32Array(V * 9);
-  for (let i = 0; i < V; i++) {
-    vbo[i * 9] = pos[i * 3]; vbo[i * 9 + 1] = pos[i * 3 + 1]; vbo[i * 9 + 2] = pos[i * 3 + 2];
-    vbo[i * 9 + 3] = nrm[i * 3]; vbo[i * 9 + 4] = nrm[i * 3 + 1]; vbo[i * 9 + 5] = nrm[i * 3 + 2];
-    vbo[i * 9 + 6] = col[i * 3]; vbo[i * 9 + 7] = col[i * 3 + 1]; vbo[i * 9 + 8] = col[i * 3 + 2];
-  }
-  if (!textured) return { vbo, idx: new Uint32Array(idx) };
-  const uv8 = new Uint16Array((idx.length / 3) * 8);
-  for (const [t, row] of uvRows) uv8.set(row, t * 8);
-  return { vbo, idx: new Uint32Array(idx), uv8 };
+  for (const plane of listOf('planes')) emitPlane(mesh, plane, colorOf(plane));
+  for (const sphere of listOf('spheres')) emitSphere(mesh, sphere, colorOf(sphere));
+  if (textured) for (const quad of listOf('quads')) emitQuad(mesh, quad, colorOf(quad));
+  return mesh.finish(textured);
 }
 
 // Typed-array fast path: indexed mesh -> the reference's unshared, flat-shaded layout without any

@@ -22,82 +22,98 @@ export function raytraceLimits() {
   return { MAX_SPHERES: pick(LIM.MAX_SPHERES, 32), MAX_PLANES: pick(LIM.MAX_PLANES, 16), MAX_TRIS: pick(LIM.MAX_TRIS, 64), MAX_MATS: 64, MAX_PL: 8, MAX_DL: 2 };
 }
 
-// raytrace.js:140-193: unified scenes pass through; the legacy shape gets one material per primitive
+// The legacy scene shape {spheres: [{p, r, m}], planes: [{p: [nx, ny, nz, d], m}], tris: [{a, b, c, m}], envLight,
+// dirLight} in unified form (raytrace.js:140-193): every primitive gets a material of its own, made from its legacy
+// material number m (0 counts as 1) - palette colour or grey, a mirror when m is above 4.  Scenes that already have a
+// geometry, materials or lights member pass through untouched.
+const LEGACY_KINDS = [
+  ['spheres', (s, mat) => ({ p: s.p, r: s.r, mat })],
+  ['planes', (pl, mat) => ({ n: [pl.p[0], pl.p[1], pl.p[2]], d: pl.p[3], mat })],
+  ['tris', (t, mat) => ({ a: t.a, b: t.b, c: t.c, mat })],
+];
+
 export function resolveUnified(scene) {
-  const S = scene || {};
-  if (S.geometry || S.materials || S.lights) return S;
-  const uni = { camera: S.camera || null, geometry: { spheres: [], planes: [], tris: [] }, materials: [],
-    lights: { points: [], directionals: [], env: { color: [0, 0, 0], intensity: 0 } } };
-  const pushMatFromM = (m) => {
-    const idx = uni.materials.length;
-    uni.materials.push({ albedo: LEGACY_PALETTE[m | 0] || [0.8, 0.8, 0.8], emissive: false, emission: [0, 0, 0], reflective: (m | 0) > 4, roughness: 0 });
-    return idx;
+  const legacy = scene || {};
+  if (legacy.geometry || legacy.materials || legacy.lights) return legacy;
+  const materials = [], geometry = {};
+  for (const [kind, convert] of LEGACY_KINDS) {
+    geometry[kind] = (legacy[kind] || []).map((prim) => {
+      const number = (prim.m || 1) | 0;
+      materials.push({ albedo: LEGACY_PALETTE[number] || [0.8, 0.8, 0.8], emissive: false, emission: [0, 0, 0], reflective: number > 4, roughness: 0 });
+      return convert(prim, materials.length - 1);
+    });
+  }
+  const sky = legacy.envLight, sun = legacy.dirLight;
+  return {
+    camera: legacy.camera || null, geometry, materials,
+    lights: {
+      points: [],
+      directionals: sun ? [{ dir: sun.dir || [0, -1, 0], color: sun.color || [1, 1, 1], intensity: sun.intensity || 0 }] : [],
+      env: sky ? { color: sky.color || [0, 0, 0], intensity: sky.intensity || 0 } : { color: [0, 0, 0], intensity: 0 },
+    },
   };
-  (S.spheres || []).forEach((s) => uni.geometry.spheres.push({ p: s.p, r: s.r, mat: pushMatFromM(s.m || 1) }));
-  (S.planes || []).forEach((p) => uni.geometry.planes.push({ n: [p.p[0], p.p[1], p.p[2]], d: p.p[3], mat: pushMatFromM(p.m || 1) }));
-  (S.tris || []).forEach((t) => uni.geometry.tris.push({ a: t.a, b: t.b, c: t.c, mat: pushMatFromM(t.m || 1) }));
-  if (S.envLight) uni.lights.env = { color: S.envLight.color || [0, 0, 0], intensity: S.envLight.intensity || 0 };
-  if (S.dirLight) uni.lights.directionals.push({ dir: S.dirLight.dir || [0, -1, 0], color: S.dirLight.color || [1, 1, 1], intensity: S.dirLight.intensity || 0 });
-  return uni;
 }
 
-const num = (v) => +v || 0;
-const at = (a, i) => (a === undefined || a === null ? undefined : a[i]);
+// A scene value as the reference coerces it on its way into a Float32Array: anything that is not a number (missing,
+// NaN) becomes 0.
+const scalar = (v) => +v || 0;
+const component = (vec, k) => (vec === undefined || vec === null ? 0 : scalar(vec[k]));
+const scaled = (vec, k, factor) => scalar(vec[k]) * factor;
 
-// raytrace.js:195-312: fixed-size arrays plus counts, exactly as they go to the uniforms
+// One row per uniform array the reference's ray tracer uploads (raytrace.js:195-312): which list of the unified scene
+// feeds it, which limit caps it, and how one list item becomes the array's elements.  `columns` name the typed arrays
+// of the packed scene: [key, array type, elements per item, item -> elements].
+const RT_GROUPS = [
+  { count: 'sphereCount', limit: 'MAX_SPHERES', items: (u) => (u.geometry || {}).spheres || [], columns: [
+    ['sphereGeom', Float32Array, 4, (s) => [component(s.p, 0), component(s.p, 1), component(s.p, 2), scalar(s.r)]],
+    ['sphereMaterial', Int32Array, 1, (s) => [s.mat | 0]]] },
+  { count: 'planeCount', limit: 'MAX_PLANES', items: (u) => (u.geometry || {}).planes || [], columns: [
+    ['planeGeom', Float32Array, 4, (p) => { const n = p.n || [0, 1, 0]; return [scalar(n[0]), scalar(n[1]), scalar(n[2]), scalar(p.d)]; }],
+    ['planeMaterial', Int32Array, 1, (p) => [p.mat | 0]]] },
+  { count: 'triCount', limit: 'MAX_TRIS', items: (u) => (u.geometry || {}).tris || [], columns: [
+    ['triA', Float32Array, 3, (t) => [0, 1, 2].map((k) => component(t.a, k))],
+    ['triB', Float32Array, 3, (t) => [0, 1, 2].map((k) => component(t.b, k))],
+    ['triC', Float32Array, 3, (t) => [0, 1, 2].map((k) => component(t.c, k))],
+    ['triMaterial', Int32Array, 1, (t) => [t.mat | 0]]] },
+  // (a materials member that is not an array has no length: the minimum is NaN, no entry is read and the count reads 0;
+  // an empty array gets one default material, below)
+  { count: 'materialCount', limit: 'MAX_MATS', items: (u) => u.materials || [], holes: true, columns: [
+    ['materialAlbedo', Float32Array, 3, (m) => [0, 1, 2].map((k) => component(m.albedo, k))],
+    ['materialMirror', Int32Array, 1, (m) => [m.reflective ? 1 : 0]]] },
+  { count: 'pointCount', limit: 'MAX_PL', items: (u) => (Array.isArray((u.lights || {}).points) ? u.lights.points : []), columns: [
+    ['pointPos', Float32Array, 3, (l) => { const p = l.p || [0, 0, 0]; return [0, 1, 2].map((k) => scalar(p[k])); }],
+    ['pointColor', Float32Array, 3, (l) => { const c = l.color || [1, 1, 1], w = scalar(l.intensity); return [0, 1, 2].map((k) => scaled(c, k, w)); }]] },
+  { count: 'dirCount', limit: 'MAX_DL', items: (u) => (Array.isArray((u.lights || {}).directionals) ? u.lights.directionals : []), columns: [
+    ['dirDir', Float32Array, 3, (l) => { const d = l.dir || [0, -1, 0]; return [0, 1, 2].map((k) => scalar(d[k])); }],
+    ['dirColor', Float32Array, 3, (l) => { const c = l.color || [1, 1, 1], w = scalar(l.intensity); return [0, 1, 2].map((k) => scaled(c, k, w)); }]] },
+];
+
+// Scene -> the fixed-size arrays and counts of the ray tracer's uniforms, byte for byte what the reference uploads
+// (raytrace.js:195-312), under this build's own names: sphereCount / sphereGeom (x, y, z, r) / sphereMaterial,
+// planeCount / planeGeom (n, d) / planeMaterial, triCount / triA / triB / triC / triMaterial, materialCount /
+// materialAlbedo / materialMirror, pointCount / pointPos / pointColor, dirCount / dirDir / dirColor, environment.
 export function packRaytraceScene(scene, limits) {
-  const L = limits || raytraceLimits(), U = resolveUnified(scene);
-  const G = U.geometry || {};
-  const spheres = G.spheres || [], planes = G.planes || [], tris = G.tris || [], mats = U.materials || [], lights = U.lights || {};
-  const S4 = new Float32Array(L.MAX_SPHERES * 4), Si = new Int32Array(L.MAX_SPHERES);
-  const P4 = new Float32Array(L.MAX_PLANES * 4), Pi = new Int32Array(L.MAX_PLANES);
-  const Ta = new Float32Array(L.MAX_TRIS * 3), Tb = new Float32Array(L.MAX_TRIS * 3), Tc = new Float32Array(L.MAX_TRIS * 3), Ti = new Int32Array(L.MAX_TRIS);
-  const Ma = new Float32Array(L.MAX_MATS * 3), Mr = new Int32Array(L.MAX_MATS);
-  let numMats = Math.min(mats.length, L.MAX_MATS);            // NaN when materials is not an array: no entry is read
-  for (let i = 0; i < numMats; i++) {
-    const m = mats[i] || {};
-    Ma[i * 3] = num(at(m.albedo, 0)); Ma[i * 3 + 1] = num(at(m.albedo, 1)); Ma[i * 3 + 2] = num(at(m.albedo, 2));
-    Mr[i] = m.reflective ? 1 : 0;
-  }
-  if (numMats === 0) { Ma[0] = Ma[1] = Ma[2] = 0.8; Mr[0] = 0; numMats = 1; }
-  const numS = Math.min(spheres.length, L.MAX_SPHERES);
-  for (let i = 0; i < numS; i++) {
-    const s = spheres[i];
-    S4[i * 4] = num(at(s.p, 0)); S4[i * 4 + 1] = num(at(s.p, 1)); S4[i * 4 + 2] = num(at(s.p, 2)); S4[i * 4 + 3] = num(s.r);
-    Si[i] = s.mat | 0;
-  }
-  const numP = Math.min(planes.length, L.MAX_PLANES);
-  for (let i = 0; i < numP; i++) {
-    const p = planes[i], n = p.n || [0, 1, 0];
-    P4[i * 4] = num(n[0]); P4[i * 4 + 1] = num(n[1]); P4[i * 4 + 2] = num(n[2]); P4[i * 4 + 3] = num(p.d);
-    Pi[i] = p.mat | 0;
-  }
-  const numT = Math.min(tris.length, L.MAX_TRIS);
-  for (let i = 0; i < numT; i++) {
-    const t = tris[i];
-    for (let k = 0; k < 3; k++) { Ta[i * 3 + k] = num(at(t.a, k)); Tb[i * 3 + k] = num(at(t.b, k)); Tc[i * 3 + k] = num(at(t.c, k)); }
-    Ti[i] = t.mat | 0;
-  }
-  const Ppos = new Float32Array(L.MAX_PL * 3), Pcol = new Float32Array(L.MAX_PL * 3), Ddir = new Float32Array(L.MAX_DL * 3), Dcol = new Float32Array(L.MAX_DL * 3);
-  let numPL = 0, numDL = 0;
-  if (Array.isArray(lights.points)) {
-    numPL = Math.min(lights.points.length, L.MAX_PL);
-    for (let i = 0; i < numPL; i++) {
-      const Lp = lights.points[i], p = Lp.p || [0, 0, 0], c = Lp.color || [1, 1, 1], k = num(Lp.intensity);
-      for (let q = 0; q < 3; q++) { Ppos[i * 3 + q] = num(p[q]); Pcol[i * 3 + q] = num(c[q]) * k; }
+  const caps = limits || raytraceLimits(), unified = resolveUnified(scene);
+  const packed = {};
+  for (const group of RT_GROUPS) {
+    const items = group.items(unified), cap = caps[group.limit];
+    const n = Math.min(items.length, cap);
+    for (const [key, ArrayType, width] of group.columns) packed[key] = new ArrayType(cap * width);
+    for (let i = 0; i < n; i++) {
+      const item = group.holes ? (items[i] || {}) : items[i];
+      for (const [key, , width, elements] of group.columns) packed[key].set(elements(item), i * width);
     }
+    packed[group.count] = n;
   }
-  if (Array.isArray(lights.directionals)) {
-    numDL = Math.min(lights.directionals.length, L.MAX_DL);
-    for (let i = 0; i < numDL; i++) {
-      const Ld = lights.directionals[i], d = Ld.dir || [0, -1, 0], c = Ld.color || [1, 1, 1], k = num(Ld.intensity);
-      for (let q = 0; q < 3; q++) { Ddir[i * 3 + q] = num(d[q]); Dcol[i * 3 + q] = num(c[q]) * k; }
-    }
+  if (packed.materialCount === 0) {                     // no materials at all: one diffuse grey (raytrace.js:237-241)
+    packed.materialAlbedo.fill(0.8, 0, 3);
+    packed.materialMirror[0] = 0;
+    packed.materialCount = 1;
   }
-  const e = lights.env, ek = e ? num(e.intensity) : 0;
-  const envCol = new Float32Array(e ? [num(at(e.color, 0)) * ek, num(at(e.color, 1)) * ek, num(at(e.color, 2)) * ek] : [0, 0, 0]);
-  return { numS: numS | 0, S4, Si, numP: numP | 0, P4, Pi, numT: numT | 0, Ta, Tb, Tc, Ti, numMats: numMats | 0, Ma, Mr,
-    numPL: numPL | 0, Ppos, Pcol, numDL: numDL | 0, Ddir, Dcol, envCol };
+  for (const group of RT_GROUPS) packed[group.count] |= 0;
+  const env = (unified.lights || {}).env, weight = env ? scalar(env.intensity) : 0;
+  packed.environment = new Float32Array(env ? [0, 1, 2].map((k) => component(env.color, k) * weight) : [0, 0, 0]);
+  return packed;
 }
 
 // Frame uniforms of raytrace.js:330-346.
@@ -114,7 +130,7 @@ export class HipRaytraceBackend {
     this._device = (opts && opts.device) | 0;
     this._h = null;
     this._scene = null;
-    this._cache = null;
+    this._packed = null;
     this._width = 0; this._height = 0;
     this._lastTopDown = null;
   }
@@ -130,8 +146,8 @@ export class HipRaytraceBackend {
   setScene(scene) {
     this._scene = scene || null;
     this._ensure();
-    this._cache = packRaytraceScene(this._scene);       // the reference packs a null scene too (raytrace.js:135-138)
-    native().rtSetScene(this._h, this._cache);
+    this._packed = packRaytraceScene(this._scene);       // the reference packs a null scene too (raytrace.js:135-138)
+    native().rtSetScene(this._h, this._packed);
   }
 
   render(_timeSec, framebuffer, appState) {

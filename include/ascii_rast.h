@@ -158,7 +158,9 @@ int ar_set_stream(ar_ctx *ctx, void *hip_stream);
  * context's: frame row r is written at d_ascii + (r - first_row) * cols, only for the rows of the
  * current strip, so a strip can be written densely into a slot of a larger gather buffer.  While a
  * target is set, ar_read / ar_render return the ASCII plane of the last frame rendered without one.
- * d_ascii must be 4-byte aligned.  NULL returns to the context's own buffer.  No counterpart in the reference. */
+ * d_ascii must be 4-byte aligned for frames whose row length is a multiple of four (codes are then stored four at a
+ * time; such a frame fails with AR_E_ARG otherwise); any address will do for other row lengths.  NULL returns to the
+ * context's own buffer.  No counterpart in the reference. */
 int ar_set_ascii_target(ar_ctx *ctx, void *d_ascii, int first_row);
 
 /* Stream-ordered hand-over of the outputs, without blocking the host (no counterpart in the reference;
@@ -179,8 +181,9 @@ int ar_quantize(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *a
 /* ar_quantize for callers that cannot allocate: same arguments, same result, but the grid and the ASCII plane are
  * staged in a fixed device array that is part of the library's code object (AR_STATIC_MAX_CELLS x 5 bytes on every
  * GPU the library runs on, held until the process ends), so the call makes no hipMalloc / hipFree.  It has NO
- * counterpart in the reference; it exists for callers under HIP graph capture, tight serving loops and harnesses that
- * forbid allocation.  Grids of more than AR_STATIC_MAX_CELLS cells are rejected with AR_E_ARG.  All calls on one GPU
+ * counterpart in the reference; it exists for callers that cannot allocate: tight serving loops, harnesses that
+ * forbid allocation, threads that run while another captures a HIP graph (the call itself waits for its stream and
+ * copies host memory, so it cannot be part of a capture).  Grids of more than AR_STATIC_MAX_CELLS cells are rejected with AR_E_ARG.  All calls on one GPU
  * share the array (whatever context they are made on): calls that overlap on one GPU race. */
 #define AR_STATIC_MAX_CELLS (1920 * 1080)
 int ar_quantize_static(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *ascii);

@@ -97,17 +97,19 @@ const sha = (ta) => crypto.createHash('sha256').update(Buffer.from(ta.buffer, ta
   assert.deepStrictEqual(rt.raytraceLimits(), rtRef.cases[0].limits); results.checks++;
   for (const c of rtRef.cases) {
     const P = rt.packRaytraceScene(rtRef.scenes[c.scene], c.limits), U = c.uniforms, tag = ' (' + c.scene + ')';
-    const counts = { uNumS: P.numS, uNumP: P.numP, uNumT: P.numT, uNumMats: P.numMats, uNumPL: P.numPL, uNumDL: P.numDL };
+    const counts = { uNumS: P.sphereCount, uNumP: P.planeCount, uNumT: P.triCount, uNumMats: P.materialCount, uNumPL: P.pointCount, uNumDL: P.dirCount };
     for (const [k, v] of Object.entries(counts)) ok(U[k] === v, k + tag);
-    const arrays = [['uSpheres[0]', P.S4, P.numS, f32], ['uSm[0]', P.Si, P.numS, i32], ['uPlanes[0]', P.P4, P.numP, f32], ['uPm[0]', P.Pi, P.numP, i32],
-      ['uTa[0]', P.Ta, P.numT, f32], ['uTb[0]', P.Tb, P.numT, f32], ['uTc[0]', P.Tc, P.numT, f32], ['uTm[0]', P.Ti, P.numT, i32],
-      ['uMatAlbedo[0]', P.Ma, P.numMats, f32], ['uMatReflective[0]', P.Mr, P.numMats, i32],
-      ['uPLPos[0]', P.Ppos, P.numPL, f32], ['uPLCol[0]', P.Pcol, P.numPL, f32], ['uDLDir[0]', P.Ddir, P.numDL, f32], ['uDLCol[0]', P.Dcol, P.numDL, f32]];
+    const arrays = [['uSpheres[0]', P.sphereGeom, P.sphereCount, f32], ['uSm[0]', P.sphereMaterial, P.sphereCount, i32],
+      ['uPlanes[0]', P.planeGeom, P.planeCount, f32], ['uPm[0]', P.planeMaterial, P.planeCount, i32],
+      ['uTa[0]', P.triA, P.triCount, f32], ['uTb[0]', P.triB, P.triCount, f32], ['uTc[0]', P.triC, P.triCount, f32], ['uTm[0]', P.triMaterial, P.triCount, i32],
+      ['uMatAlbedo[0]', P.materialAlbedo, P.materialCount, f32], ['uMatReflective[0]', P.materialMirror, P.materialCount, i32],
+      ['uPLPos[0]', P.pointPos, P.pointCount, f32], ['uPLCol[0]', P.pointColor, P.pointCount, f32],
+      ['uDLDir[0]', P.dirDir, P.dirCount, f32], ['uDLCol[0]', P.dirColor, P.dirCount, f32]];
     for (const [name, got, n, dec] of arrays) {
       if (n > 0) ok(bytesEqual(got, dec(U[name])), name + tag);       // the reference uploads an array only when its count is positive
       else ok(U[name] === undefined, name + ' must not be uploaded' + tag);
     }
-    ok(bytesEqual(P.envCol, f32(U.uEnv)), 'uEnv' + tag);
+    ok(bytesEqual(P.environment, f32(U.uEnv)), 'uEnv' + tag);
     if (c.pixelAspect === null) delete config.PATH_TRACER.PIXEL_ASPECT; else config.PATH_TRACER.PIXEL_ASPECT = c.pixelAspect;
     setCamera(c.camera.pos, c.camera.yaw, c.camera.pitch);
     const F = rt.raytraceFrameUniforms();

@@ -517,6 +517,45 @@ def test_callers_stream_ascii_target_and_stream_handover(pkg, oracle):
         r.close()
 
 
+def test_ascii_target_ring_with_an_odd_row_length(pkg, oracle):
+    """A ring of ASCII strips for a grid whose row length is not a multiple of four (333 x 27 per slot): most slots
+    start at an address that is not 4-byte aligned, which is fine because codes are stored byte by byte then; with a
+    row length that is a multiple of four a misaligned target is refused when the frame is enqueued."""
+    import torch
+    r = pkg.Renderer(0)
+    try:
+        cols, rows = 333, 81
+        sc = pkg.scenes.icosphere_scene(angle=0.4, cols=cols, rows=rows, subdiv=3)
+        for mode in ((True, 2, 12), (False, 2, 12), (True, 3, 20)):
+            pkg.scenes.upload(r, sc, pkg.scenes.DEFAULT_RAMP, *mode)
+            rgba, _d, _i = oracle.render(sc["vbo"], sc["idx"], sc["proj"], sc["view"], sc["lights"], cols, rows)
+            want = oracle.quantize(rgba, cols, rows, pkg.scenes.DEFAULT_RAMP, int(mode[0]), mode[1], mode[2])
+            ring = torch.zeros((3, 27, cols), dtype=torch.uint8, device="cuda")
+            assert any(ring[k].data_ptr() % 4 for k in range(3))
+            for k in range(3):
+                r.set_strip(27 * k, 27 * (k + 1))
+                r.set_ascii_target(ring[k].data_ptr(), 27 * k)
+                r.render_async(cols, rows)
+            r.sync()
+            assert np.array_equal(ring.cpu().numpy().reshape(rows, cols), want), mode
+            r.set_ascii_target(None)
+            r.set_strip(0, 0)
+        # a multiple of four: dword stores, so the target must be aligned
+        sc4 = pkg.scenes.icosphere_scene(angle=0.4, cols=64, rows=16, subdiv=2)
+        pkg.scenes.upload(r, sc4)
+        buf = torch.zeros(64 * 16 + 8, dtype=torch.uint8, device="cuda")
+        r.set_ascii_target(buf.data_ptr() + 1, 0)
+        with pytest.raises(pkg.AsciiRastError, match="aligned"):
+            r.render_async(64, 16)
+        r.set_ascii_target(buf.data_ptr() + 4, 0)
+        r.render_async(64, 16)
+        r.sync()
+        rgba, _d, _i = oracle.render(sc4["vbo"], sc4["idx"], sc4["proj"], sc4["view"], sc4["lights"], 64, 16)
+        assert np.array_equal(buf[4:4 + 64 * 16].cpu().numpy().reshape(16, 64), oracle.quantize(rgba, 64, 16, pkg.scenes.DEFAULT_RAMP, 1, 2, 12))
+    finally:
+        r.close()
+
+
 def test_many_tiles_take_the_direct_path(pkg, oracle):
     """More than 8000 tiles (here 8192 x 2048 cells = 8192 tiles): the library falls back to the direct path."""
     r = pkg.Renderer(0)

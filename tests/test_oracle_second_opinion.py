@@ -269,21 +269,70 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "self_consistency_fra
 
 
 def golden_cases(pkg):
-    """(name, scene) of every committed frame, in the order gen_self_consistency.py wrote them."""
+    """(name, scene) of every committed frame, in the order gen_self_consistency.py wrote them: C1 (sixty orbit angles),
+    C2 without and with point lights, and one frame of each regime most likely to drift together with the kernels - a
+    soup of triangles through the near plane (200 x 100), the cube under a model matrix, the reference's own default
+    scene (two smooth-shaded spheres, 96 x 36), that scene with its quads and atlas textured, and 64 k small triangles
+    shaped like C3 on a 320 x 180 grid."""
+    import base64
+    import json
     cases = [("c1_%02d" % k, pkg.scenes.cube_scene(angle=2 * math.pi * k / 60)) for k in range(60)]
     cases.append(("c2", pkg.scenes.icosphere_scene()))
     cases.append(("c2_lights", pkg.scenes.icosphere_scene(angle=1.9, point_lights=4)))
+    host, golden = pkg.host, os.path.join(os.path.dirname(__file__), "golden")
+    # near-plane clipping: big and small triangles around and through the camera, one point light
+    rng = np.random.default_rng(7)
+    T = 3000
+    centre = rng.uniform(-6, 6, size=(T, 1, 3))
+    P = (centre + rng.uniform(-1, 1, size=(T, 3, 3)) * rng.choice([0.05, 0.5, 4.0, 30.0], size=(T, 1, 1))).reshape(-1, 3)
+    vbo, idx = host.mesh_to_vbo(P.astype(np.float32), np.arange(T * 3).reshape(-1, 3), rng.uniform(0, 1, size=(T, 3)))
+    proj, view = host.camera_matrices({"pos": (0.1, 0.2, 0.3), "yaw": 0.7, "pitch": -0.2}, 200, 100, 0.5)
+    lights = host.pack_lights({"lights": {"points": [{"p": [1, 2, 0], "color": [1, 1, 1], "intensity": 4}]}})
+    cases.append(("clip_soup", {"name": "clip soup", "vbo": vbo, "idx": idx, "proj": proj, "view": view, "lights": lights, "cols": 200, "rows": 100}))
+    # a model matrix (rotation, translation, scale) on C1's cube
+    cases.append(("model_cube", dict(pkg.scenes.cube_scene(angle=0.6), model=pkg.geometry.spin_matrix(0.9, axis=(0.3, 1.0, 0.2), translate=(0.2, -0.1, 0.3), scale=1.3))))
+    # the reference's default scene as its rasterizer draws it: two spheres with smooth normals
+    with open(os.path.join(golden, "ref_raster_host.json")) as fh:
+        ref = json.load(fh)
+    case = next(c for c in ref["cases"] if c["scene"] == "default_scene" and c["cols"] == 96 and c["rows"] == 36)
+    scene = ref["scenes"]["default_scene"]
+    vbo, idx = host.build_geometry(scene)
+    proj, view = host.camera_matrices(case["camera"], 96, 36, case["pixelAspect"])
+    cases.append(("default_scene", {"name": "default scene", "vbo": vbo, "idx": idx, "proj": proj, "view": view, "lights": host.pack_lights(scene), "cols": 96, "rows": 36}))
+    # the same scene with its quads and the 32 x 32 atlas (ASCII overrides in the alpha bytes), facing the poster
+    with open(os.path.join(golden, "ref_pathtrace_uv.json")) as fh:
+        tcase = next(c for c in json.load(fh)["cases"] if c["name"] == "default_scene_atlas32")
+    tscene = tcase["scene"]
+    atlas = np.frombuffer(base64.b64decode(tcase["atlas_rgba"]), dtype=np.uint8).reshape(tscene["atlas"]["height"], tscene["atlas"]["width"], 4)
+    vbo, idx, uv8 = host.build_geometry(tscene, textured=True)
+    proj, view = host.camera_matrices({"pos": (0.0, 2.5, 6.0), "yaw": -math.pi / 2, "pitch": 0.0}, 120, 50, 0.5)
+    cases.append(("textured", {"name": "textured default scene", "vbo": vbo, "idx": idx, "uv8": uv8, "atlas": atlas, "proj": proj, "view": view,
+                               "lights": host.pack_lights(tscene), "cols": 120, "rows": 50}))
+    # dense small triangles: C3's distribution at 64 k triangles on a 320 x 180 grid (about three cells each)
+    cases.append(("c3_small", pkg.scenes.random_scene(65536, 320, 180, mesh_grid=(320, 180))))
     return cases
+
+
+def _oracle_frame(pkg, oracle, sc):
+    rgba, depth, _ids = oracle.render(sc["vbo"], sc["idx"], sc["proj"], sc["view"], sc["lights"], sc["cols"], sc["rows"], want_ids=False,
+                                      uv8=sc.get("uv8"), atlas=sc.get("atlas"), model=sc.get("model"))
+    return rgba, depth, oracle.quantize(rgba, sc["cols"], sc["rows"], pkg.scenes.DEFAULT_RAMP, 1, 2, 12)
 
 
 def test_oracle_reproduces_the_committed_frames(pkg, oracle):
     z = np.load(GOLDEN)
+    names = set()
     for name, sc in golden_cases(pkg):
-        rgba, depth, _ids = oracle.render(sc["vbo"], sc["idx"], sc["proj"], sc["view"], sc["lights"], sc["cols"], sc["rows"], want_ids=False)
-        asc = oracle.quantize(rgba, sc["cols"], sc["rows"], pkg.scenes.DEFAULT_RAMP, 1, 2, 12)
+        rgba, depth, asc = _oracle_frame(pkg, oracle, sc)
         assert np.array_equal(asc, z[name + "_ascii"]), name
         assert np.array_equal(depth.view(np.uint32), z[name + "_depth"].view(np.uint32)), name
         assert np.array_equal(rgba, z[name + "_rgba"]), name
+        names.update(name + suffix for suffix in ("_ascii", "_depth", "_rgba"))
+    assert names == set(z.files)
+    # the frames show what their names say
+    assert np.count_nonzero(z["clip_soup_depth"] < 1.0) > 5000 and np.count_nonzero(z["c3_small_depth"] < 1.0) > 10000
+    a = z["textured_rgba"][..., 3]
+    assert np.count_nonzero((a >= 32) & (a <= 126)) > 100 and np.all(z["default_scene_rgba"][..., 3] == 255)
 
 
 @pytest.mark.gpu
@@ -297,6 +346,7 @@ def test_hip_path_reproduces_the_committed_frames(pkg):
             for name, sc in golden_cases(pkg):
                 pkg.scenes.upload(R, sc)
                 out = R.render(sc["cols"], sc["rows"])
+                assert out["rgba"].shape == z[name + "_rgba"].shape, (path, name)
                 assert np.array_equal(out["ascii"], z[name + "_ascii"]), (path, name)
                 assert np.array_equal(out["depth"].view(np.uint32), z[name + "_depth"].view(np.uint32)), (path, name)
                 assert np.array_equal(out["rgba"], z[name + "_rgba"]), (path, name)

@@ -45,3 +45,45 @@ def test_static_quantize_equals_quantize_on_two_calls_in_a_row(pkg):
     finally:
         R.close()
         R2.close()
+
+
+def test_static_quantize_leaves_device_memory_alone(pkg):
+    """What the entry point exists for: no device allocation on the way.  A fresh context that has never run
+    ar_quantize (so the growable staging buffers do not exist) makes calls at several grid sizes and parameter sets; the
+    device's free memory, read with hipMemGetInfo before and after, must not move.  (A first context warms the same
+    kernels up beforehand: loading a kernel's code is the runtime's allocation, made once per process.)"""
+    import torch
+    rng = np.random.default_rng(23)
+    modes = ((True, 2, 12), (False, 2, 12), (True, 1, 3), (True, 3, 20))
+    grids = ((640, 360), (1920, 1080), (97, 31))
+    cases = [(m, g, _grid(rng, *g)) for m in modes for g in grids]
+    warm = pkg.Renderer(0)
+    try:
+        for mode, (cols, rows), rgba in cases:
+            warm.set_ascii("@%#*+=-:. ", *mode)
+            warm.quantize_static(rgba, cols, rows)
+        want = {}
+        for k, (mode, (cols, rows), rgba) in enumerate(cases):
+            warm.set_ascii("@%#*+=-:. ", *mode)
+            want[k] = warm.quantize(rgba, cols, rows)
+    finally:
+        warm.close()
+    R = pkg.Renderer(0)
+    try:
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info(0)[0]
+        got = {}
+        for k, (mode, (cols, rows), rgba) in enumerate(cases):
+            R.set_ascii("@%#*+=-:. ", *mode)
+            got[k] = R.quantize_static(rgba, cols, rows)
+        torch.cuda.synchronize()
+        free_after = torch.cuda.mem_get_info(0)[0]
+        assert free_after == free_before, "ar_quantize_static changed the device's free memory by %d bytes" % (free_before - free_after)
+        for k in got:
+            assert np.array_equal(got[k], want[k]), cases[k][:2]
+        # the control: the allocating entry point does move it on this context (its staging buffers do not exist yet)
+        R.quantize(cases[1][2], 1920, 1080)
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info(0)[0] < free_before
+    finally:
+        R.close()
