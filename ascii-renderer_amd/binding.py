@@ -18,6 +18,7 @@ EXPORTS = [
     "ar_set_ascii_target", "ar_quantize", "ar_quantize_colors", "ar_read_colors", "ar_present", "ar_set_profiling", "ar_kernel_stats",
     "ar_frame_counters", "ar_set_option", "ar_set_mesh_uv", "ar_set_texture", "ar_set_mesh_indexed", "ar_read_mesh",
     "ar_rt_set_scene", "ar_rt_render", "ar_rt_render_async", "ar_quantize_static", "ar_set_model",
+    "ar_read_async", "ar_wait", "ar_poll",
 ]
 _lib = None
 
@@ -86,6 +87,11 @@ def load_library():
     L.ar_render_async.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     L.ar_sync.argtypes = [vp]
     L.ar_read.argtypes = [vp, _u8p, _fp, _u8p, _u32p]
+    L.ar_read_async.argtypes = [vp, _u8p, _fp, _u8p, _u32p, ctypes.POINTER(ctypes.c_uint64)]
+    L.ar_wait.argtypes = [vp, ctypes.c_uint64]
+    L.ar_poll.argtypes = [vp, ctypes.c_uint64]
+    for name in ("ar_read_async", "ar_wait", "ar_poll"):
+        getattr(L, name).restype = ctypes.c_int
     L.ar_device_buffer.argtypes = [vp, ctypes.c_int]
     L.ar_device_buffer.restype = vp
     L.ar_stream.argtypes = [vp]
@@ -286,6 +292,9 @@ class Renderer:
     def set_strip(self, row0, row1):
         self._check(self._L.ar_set_strip(self._h, int(row0), int(row1)))
 
+    def set_id_output(self, on):
+        self._check(self._L.ar_set_id_output(self._h, int(bool(on))))
+
     def render(self, cols, rows, want_ids=False):
         """Blocking frame; returns dict(rgba, depth, ascii[, ids])."""
         self._check(self._L.ar_set_id_output(self._h, int(bool(want_ids))))
@@ -323,6 +332,27 @@ class Renderer:
             depth.ctypes.data_as(_fp) if depth is not None else None,
             ascii.ctypes.data_as(_u8p) if ascii is not None else None))
         self.cols, self.rows = int(cols), int(rows)
+
+    def read_async(self, rgba=None, depth=None, ascii=None, ids=None):
+        """Queues copies of the last enqueued frame's planes into the given host arrays (page-locked ones from
+        host_array for a copy that does not block) behind that frame and returns a ticket for wait() / poll()."""
+        t = ctypes.c_uint64(0)
+        self._check(self._L.ar_read_async(
+            self._h,
+            rgba.ctypes.data_as(_u8p) if rgba is not None else None,
+            depth.ctypes.data_as(_fp) if depth is not None else None,
+            ascii.ctypes.data_as(_u8p) if ascii is not None else None,
+            ids.ctypes.data_as(_u32p) if ids is not None else None, ctypes.byref(t)))
+        return t.value
+
+    def wait(self, ticket):
+        self._check(self._L.ar_wait(self._h, ctypes.c_uint64(int(ticket))))
+
+    def poll(self, ticket):
+        rc = self._L.ar_poll(self._h, ctypes.c_uint64(int(ticket)))
+        if rc < 0:
+            self._check(rc)
+        return rc == 1
 
     def device_buffer(self, which):
         return self._L.ar_device_buffer(self._h, {"rgba": 0, "depth": 1, "ascii": 2}[which])

@@ -96,6 +96,8 @@ ar_ctx *ar_create(int device_id) {
     ctx->fstream[0] = ctx->own_stream;
     for (int k = 1; ok && k < kSets; k++) ok = hipStreamCreateWithFlags(&ctx->fstream[k], hipStreamNonBlocking) == hipSuccess;
     for (int k = 0; ok && k <= kSets; k++) ok = hipEventCreateWithFlags(&ctx->ev_out[k], hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; ok && k <= kSets; k++)
+        for (int j = 0; ok && j < kTicketRing; j++) ok = hipEventCreateWithFlags(&ctx->ev_done[k][j], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         fail(nullptr, AR_E_HIP, "context setup failed: %s", hipGetErrorString(hipGetLastError()));
         ar_destroy(ctx);
@@ -138,8 +140,11 @@ void ar_destroy(ar_ctx *ctx) {
         (void)hipFree(ctx->d_entries[k]); (void)hipFree(ctx->d_surv[k]); (void)hipFree(ctx->d_sid[k]); (void)hipFree(ctx->d_surv_count[k]);
         (void)hipFree(ctx->d_dircount[k]);
     }
-    for (int k = 0; k <= kSets; k++)
+    for (int k = 0; k <= kSets; k++) {
         if (ctx->ev_out[k]) (void)hipEventDestroy(ctx->ev_out[k]);
+        for (int j = 0; j < kTicketRing; j++)
+            if (ctx->ev_done[k][j]) (void)hipEventDestroy(ctx->ev_done[k][j]);
+    }
     if (ctx->ev_ext) (void)hipEventDestroy(ctx->ev_ext);
     for (int k = 1; k < kSets; k++)
         if (ctx->fstream[k]) (void)hipStreamDestroy(ctx->fstream[k]);
@@ -340,6 +345,69 @@ int ar_render(ar_ctx *ctx, int cols, int rows, uint8_t *rgba, float *depth, uint
     if (ctx->n_tris == 0 || !ctx->rendered) return ar_sync(ctx);  // no geometry: outputs stay untouched (raster.js:274)
     // a blocking frame runs on ctx->stream alone (enqueue_frame has waited for any overlapped frames before it)
     return read_outputs(ctx, ctx->stream, rgba, depth, ascii, nullptr);
+}
+
+int ar_read_async(ar_ctx *ctx, uint8_t *rgba, float *depth, uint8_t *ascii, uint32_t *ids, uint64_t *ticket) {
+    if (!ctx) return AR_E_ARG;
+    if (!ticket) return fail(ctx, AR_E_ARG, "ar_read_async: null ticket");
+    if (!ctx->rendered || !ctx->last_stream) return fail(ctx, AR_E_STATE, "ar_read_async: no frame has been rendered at this grid size");
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = size_t(ctx->cols) * ctx->rows;
+    const int o = ctx->last_oset, slot = ctx->last_slot;
+    hipStream_t s = ctx->last_stream;
+    if (ids && !ctx->d_ids[o]) return fail(ctx, AR_E_STATE, "ar_read_async: ids wanted but ar_set_id_output was not on for the last frame");
+    hipError_t e = hipSuccess;
+    if (rgba && e == hipSuccess) e = hipMemcpyAsync(rgba, ctx->d_rgba[o], n * 4, hipMemcpyDeviceToHost, s);
+    if (depth && e == hipSuccess) e = hipMemcpyAsync(depth, ctx->d_depth[o], n * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (ascii && e == hipSuccess) e = hipMemcpyAsync(ascii, ctx->d_ascii[o], n, hipMemcpyDeviceToHost, s);
+    if (ids && e == hipSuccess) e = hipMemcpyAsync(ids, ctx->d_ids[o], n * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    const uint64_t serial = ctx->slot_serial[slot] + 1;
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_done[slot][serial % kTicketRing], s);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(s);  // no copy into the caller's memory may outlive a failed call
+        return fail(ctx, AR_E_HIP, "ar_read_async: %s", hipGetErrorString(e));
+    }
+    ctx->slot_serial[slot] = serial;
+    *ticket = (serial << 2) | uint64_t(slot);
+    return 0;
+}
+
+namespace {
+
+// The event behind a ticket, or null (message set) when the ticket was never issued by this context.  A slot keeps the
+// events of its last kTicketRing tickets apart; a ticket older than that waits for the slot's newest event, which was
+// recorded later on the same stream and therefore covers it.
+hipEvent_t ticket_event(ar_ctx *ctx, uint64_t ticket, const char *who) {
+    const uint64_t serial = ticket >> 2;
+    const int slot = int(ticket & 3u);
+    if (slot > kSets || serial == 0 || ctx->slot_serial[slot] < serial) {
+        fail(ctx, AR_E_ARG, "%s: ticket %llu was not issued by this context", who, static_cast<unsigned long long>(ticket));
+        return nullptr;
+    }
+    const uint64_t newest = ctx->slot_serial[slot];
+    return ctx->ev_done[slot][(newest - serial < uint64_t(kTicketRing) ? serial : newest) % kTicketRing];
+}
+
+}  // namespace
+
+int ar_wait(ar_ctx *ctx, uint64_t ticket) {
+    if (!ctx) return AR_E_ARG;
+    hipEvent_t ev = ticket_event(ctx, ticket, "ar_wait");
+    if (!ev) return AR_E_ARG;
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    AR_HIP(ctx, hipEventSynchronize(ev));
+    return 0;
+}
+
+int ar_poll(ar_ctx *ctx, uint64_t ticket) {
+    if (!ctx) return AR_E_ARG;
+    hipEvent_t ev = ticket_event(ctx, ticket, "ar_poll");
+    if (!ev) return AR_E_ARG;
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    return fail(ctx, AR_E_HIP, "ar_poll: %s", hipGetErrorString(e));
 }
 
 void *ar_device_buffer(ar_ctx *ctx, int which) {
@@ -590,6 +658,8 @@ int ar_rt_render_async(ar_ctx *ctx, int cols, int rows, const float cam_pos[3], 
     AR_HIP(ctx, hipGetLastError());
     ctx->rendered = true;
     ctx->last_oset = 0;
+    ctx->last_stream = ctx->stream;
+    ctx->last_slot = kSets;
     return 0;
 }
 

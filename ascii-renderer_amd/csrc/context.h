@@ -8,6 +8,8 @@ thread_local char g_create_error[256] = "";
 
 }  // namespace
 
+constexpr int kTicketRing = 8;  // tickets per stream whose events are kept apart (older ones wait for a newer event of the same stream)
+
 struct ar_ctx {
     int device = 0;
     hipStream_t stream = nullptr;   // stream of frames that do not overlap, of quantize / present and of copies: own_stream
@@ -21,6 +23,12 @@ struct ar_ctx {
     int overlap = 1;                // 0: frames one after the other on `stream`; 1: consecutive frames rotate over the frame streams
     hipEvent_t ev_out[kSets + 1] = {};  // outputs complete on each frame stream / on `stream` (ar_stream_wait_frame)
     hipEvent_t ev_ext = nullptr;    // a caller's stream has consumed the outputs (ar_frame_wait_stream)
+    // pipelined read-back (ar_read_async / ar_wait): a ring of events per frame stream and one for `stream`, each recorded
+    // behind the copies of one frame; a ticket is (serial on its slot << 2 | slot), slot_serial[] the newest serial of a slot
+    hipEvent_t ev_done[kSets + 1][kTicketRing] = {};
+    uint64_t slot_serial[kSets + 1] = {};
+    hipStream_t last_stream = nullptr;  // stream the most recent frame was enqueued on
+    int last_slot = kSets;              // its event slot: the buffer set of an overlapped frame, kSets for `stream`
     float *d_vbo = nullptr;
     uint32_t *d_idx = nullptr;
     uint32_t n_verts = 0, n_tris = 0;
@@ -454,6 +462,8 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
     ctx->rendered = true;
     ctx->last_tiled = tiled;
     ctx->last_oset = oset;
+    ctx->last_stream = fs;
+    ctx->last_slot = overlap ? set : kSets;
     return 0;
 }
 

@@ -3,6 +3,7 @@
 // Every export is a one-to-one wrapper: typed arrays in, status out.  Setup calls throw a JS Error
 // carrying ar_last_error(); nothing here computes anything.  The handle returned by create() is an
 // external whose finalizer destroys the context if the host forgot to.
+#define NAPI_VERSION 6
 #include <node_api.h>
 
 #include <cstdint>
@@ -509,6 +510,266 @@ napi_value js_frame_counters(napi_env env, napi_callback_info info) {
     return arr;
 }
 
+// A device or stream address crosses the boundary as a BigInt (exact) or, from callers that computed it, a Number.
+bool get_address(napi_env env, napi_value v, void **out) {
+    napi_valuetype vt;
+    napi_typeof(env, v, &vt);
+    *out = nullptr;
+    if (vt == napi_null || vt == napi_undefined) return true;
+    if (vt == napi_bigint) {
+        uint64_t x = 0;
+        bool lossless = false;
+        if (napi_get_value_bigint_uint64(env, v, &x, &lossless) != napi_ok || !lossless) {
+            napi_throw_range_error(env, nullptr, "ascii_rast addon: address out of range");
+            return false;
+        }
+        *out = reinterpret_cast<void *>(uintptr_t(x));
+        return true;
+    }
+    if (vt == napi_number) {
+        double d = 0;
+        napi_get_value_double(env, v, &d);
+        if (!(d >= 0) || d > 9007199254740992.0) { napi_throw_range_error(env, nullptr, "ascii_rast addon: address out of range"); return false; }
+        *out = reinterpret_cast<void *>(uintptr_t(d));
+        return true;
+    }
+    napi_throw_type_error(env, nullptr, "ascii_rast addon: address (BigInt, Number or null) expected");
+    return false;
+}
+
+napi_value make_address(napi_env env, const void *p) {
+    napi_value v = nullptr;
+    if (napi_create_bigint_uint64(env, uint64_t(reinterpret_cast<uintptr_t>(p)), &v) != napi_ok) {
+        napi_throw_error(env, nullptr, "ascii_rast addon: cannot create a BigInt");
+        return nullptr;
+    }
+    return v;
+}
+
+bool get_ticket(napi_env env, napi_value v, uint64_t *ticket) {
+    double d = -1;
+    if (napi_get_value_double(env, v, &d) != napi_ok || !(d >= 0) || d > 9007199254740992.0) {
+        napi_throw_type_error(env, nullptr, "ascii_rast addon: ticket (a Number returned by readAsync) expected");
+        return false;
+    }
+    *ticket = uint64_t(d);
+    return true;
+}
+
+// renderAsync(handle, cols, rows): ar_render_async - enqueue a frame and return
+napi_value js_render_async(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    if (ar_render_async(ctx, get_i32(env, argv[1]), get_i32(env, argv[2]))) return throw_ar(env, ctx, "ar_render_async");
+    return nullptr;
+}
+
+// readAsync(handle, cols, rows, rgba|null, depth|null, ascii|null, ids|null) -> ticket (Number): ar_read_async.  The
+// arrays must stay alive (and should be page-locked, allocHost) until wait(ticket) has returned.
+napi_value js_read_async(napi_env env, napi_callback_info info) {
+    napi_value argv[7];
+    if (!get_args(env, info, 7, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    const int cols = get_i32(env, argv[1]), rows = get_i32(env, argv[2]);
+    void *rgba, *depth, *ascii, *ids;
+    size_t nr, nd, na, ni;
+    if (!get_typed(env, argv[3], napi_uint8_array, &rgba, &nr, true) || !get_typed(env, argv[4], napi_float32_array, &depth, &nd, true) ||
+        !get_typed(env, argv[5], napi_uint8_array, &ascii, &na, true) || !get_typed(env, argv[6], napi_uint32_array, &ids, &ni, true))
+        return nullptr;
+    const size_t n = size_t(cols > 0 ? cols : 0) * size_t(rows > 0 ? rows : 0);
+    if ((rgba && nr != n * 4) || (depth && nd != n) || (ascii && na != n) || (ids && ni != n)) {
+        napi_throw_range_error(env, nullptr, "readAsync: output array size does not match cols*rows");
+        return nullptr;
+    }
+    uint64_t ticket = 0;
+    if (ar_read_async(ctx, static_cast<uint8_t *>(rgba), static_cast<float *>(depth), static_cast<uint8_t *>(ascii), static_cast<uint32_t *>(ids), &ticket))
+        return throw_ar(env, ctx, "ar_read_async");
+    napi_value out;
+    NAPI_OK(env, napi_create_double(env, double(ticket), &out));
+    return out;
+}
+
+napi_value js_wait(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    uint64_t ticket;
+    if (!ctx || !get_ticket(env, argv[1], &ticket)) return nullptr;
+    if (ar_wait(ctx, ticket)) return throw_ar(env, ctx, "ar_wait");
+    return nullptr;
+}
+
+// poll(handle, ticket) -> true when the frame and its copies are complete
+napi_value js_poll(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    uint64_t ticket;
+    if (!ctx || !get_ticket(env, argv[1], &ticket)) return nullptr;
+    const int rc = ar_poll(ctx, ticket);
+    if (rc < 0) return throw_ar(env, ctx, "ar_poll");
+    napi_value out;
+    napi_get_boolean(env, rc == 1, &out);
+    return out;
+}
+
+napi_value js_sync(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    if (ar_sync(ctx)) return throw_ar(env, ctx, "ar_sync");
+    return nullptr;
+}
+
+// read(handle, cols, rows, rgba|null, depth|null, ascii|null, ids|null): ar_read (blocking copy of the last frame)
+napi_value js_read(napi_env env, napi_callback_info info) {
+    napi_value argv[7];
+    if (!get_args(env, info, 7, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    const int cols = get_i32(env, argv[1]), rows = get_i32(env, argv[2]);
+    void *rgba, *depth, *ascii, *ids;
+    size_t nr, nd, na, ni;
+    if (!get_typed(env, argv[3], napi_uint8_array, &rgba, &nr, true) || !get_typed(env, argv[4], napi_float32_array, &depth, &nd, true) ||
+        !get_typed(env, argv[5], napi_uint8_array, &ascii, &na, true) || !get_typed(env, argv[6], napi_uint32_array, &ids, &ni, true))
+        return nullptr;
+    const size_t n = size_t(cols > 0 ? cols : 0) * size_t(rows > 0 ? rows : 0);
+    if ((rgba && nr != n * 4) || (depth && nd != n) || (ascii && na != n) || (ids && ni != n)) {
+        napi_throw_range_error(env, nullptr, "read: output array size does not match cols*rows");
+        return nullptr;
+    }
+    if (ar_read(ctx, static_cast<uint8_t *>(rgba), static_cast<float *>(depth), static_cast<uint8_t *>(ascii), static_cast<uint32_t *>(ids)))
+        return throw_ar(env, ctx, "ar_read");
+    return nullptr;
+}
+
+// deviceBuffer(handle, which) -> BigInt device address (0n before the first frame): ar_device_buffer
+napi_value js_device_buffer(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    return make_address(env, ar_device_buffer(ctx, get_i32(env, argv[1])));
+}
+
+// stream(handle) -> BigInt hipStream_t: ar_stream
+napi_value js_stream(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    return make_address(env, ar_stream(ctx));
+}
+
+napi_value js_set_stream(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    void *s;
+    if (!ctx || !get_address(env, argv[1], &s)) return nullptr;
+    if (ar_set_stream(ctx, s)) return throw_ar(env, ctx, "ar_set_stream");
+    return nullptr;
+}
+
+// setAsciiTarget(handle, address|null, firstRow): ar_set_ascii_target
+napi_value js_set_ascii_target(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    void *p;
+    if (!ctx || !get_address(env, argv[1], &p)) return nullptr;
+    if (ar_set_ascii_target(ctx, p, get_i32(env, argv[2]))) return throw_ar(env, ctx, "ar_set_ascii_target");
+    return nullptr;
+}
+
+napi_value js_stream_wait_frame(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    void *s;
+    if (!ctx || !get_address(env, argv[1], &s)) return nullptr;
+    if (ar_stream_wait_frame(ctx, s)) return throw_ar(env, ctx, "ar_stream_wait_frame");
+    return nullptr;
+}
+
+napi_value js_frame_wait_stream(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    void *s;
+    if (!ctx || !get_address(env, argv[1], &s)) return nullptr;
+    if (ar_frame_wait_stream(ctx, s)) return throw_ar(env, ctx, "ar_frame_wait_stream");
+    return nullptr;
+}
+
+napi_value js_set_profiling(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    bool on = false;
+    napi_get_value_bool(env, argv[1], &on);
+    if (ar_set_profiling(ctx, on ? 1 : 0)) return throw_ar(env, ctx, "ar_set_profiling");
+    return nullptr;
+}
+
+// kernelStats(handle) -> { kernelName: { launches, ms } } for the kernels launched since the last call: ar_kernel_stats
+napi_value js_kernel_stats(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    const char *names[AR_N_KERNELS];
+    uint32_t launches[AR_N_KERNELS];
+    float ms[AR_N_KERNELS];
+    if (ar_kernel_stats(ctx, names, launches, ms)) return throw_ar(env, ctx, "ar_kernel_stats");
+    napi_value out;
+    NAPI_OK(env, napi_create_object(env, &out));
+    for (int k = 0; k < AR_N_KERNELS; k++) {
+        if (!names[k] || !names[k][0] || !launches[k]) continue;
+        napi_value rec, n, t;
+        NAPI_OK(env, napi_create_object(env, &rec));
+        NAPI_OK(env, napi_create_uint32(env, launches[k], &n));
+        NAPI_OK(env, napi_create_double(env, double(ms[k]), &t));
+        NAPI_OK(env, napi_set_named_property(env, rec, "launches", n));
+        NAPI_OK(env, napi_set_named_property(env, rec, "ms", t));
+        NAPI_OK(env, napi_set_named_property(env, out, names[k], rec));
+    }
+    return out;
+}
+
+// readColors(handle, cols, rows, steps, grayscale, outUint32Array): ar_read_colors of the last rendered frame
+napi_value js_read_colors(napi_env env, napi_callback_info info) {
+    napi_value argv[6];
+    if (!get_args(env, info, 6, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    const int cols = get_i32(env, argv[1]), rows = get_i32(env, argv[2]);
+    void *colors;
+    size_t nc;
+    if (!get_typed(env, argv[5], napi_uint32_array, &colors, &nc, false)) return nullptr;
+    if (nc != size_t(cols > 0 ? cols : 0) * size_t(rows > 0 ? rows : 0)) { napi_throw_range_error(env, nullptr, "readColors: array size does not match cols*rows"); return nullptr; }
+    bool gray = false;
+    napi_get_value_bool(env, argv[4], &gray);
+    if (ar_read_colors(ctx, get_i32(env, argv[3]), gray ? 1 : 0, static_cast<uint32_t *>(colors))) return throw_ar(env, ctx, "ar_read_colors");
+    return nullptr;
+}
+
+napi_value js_set_id_output(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    bool on = false;
+    napi_get_value_bool(env, argv[1], &on);
+    if (ar_set_id_output(ctx, on ? 1 : 0)) return throw_ar(env, ctx, "ar_set_id_output");
+    return nullptr;
+}
+
 napi_value init(napi_env env, napi_value exports) {
     const napi_property_descriptor props[] = {
         {"create", nullptr, js_create, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
@@ -533,6 +794,22 @@ napi_value init(napi_env env, napi_value exports) {
         {"allocHost", nullptr, js_alloc_host, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"quantizeColors", nullptr, js_quantize_colors, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"present", nullptr, js_present, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"renderAsync", nullptr, js_render_async, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"readAsync", nullptr, js_read_async, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"wait", nullptr, js_wait, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"poll", nullptr, js_poll, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"sync", nullptr, js_sync, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"read", nullptr, js_read, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"deviceBuffer", nullptr, js_device_buffer, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"stream", nullptr, js_stream, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setStream", nullptr, js_set_stream, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setAsciiTarget", nullptr, js_set_ascii_target, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"streamWaitFrame", nullptr, js_stream_wait_frame, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"frameWaitStream", nullptr, js_frame_wait_stream, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setProfiling", nullptr, js_set_profiling, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"kernelStats", nullptr, js_kernel_stats, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"readColors", nullptr, js_read_colors, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"setIdOutput", nullptr, js_set_id_output, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
     };
     napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
     return exports;

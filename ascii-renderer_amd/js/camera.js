@@ -9,8 +9,11 @@ export const camera = {
   sensitivity: 1.5,
 };
 
+// pos: [x, y, z] or {x, y, z} (the shape of camera.pos itself)
 export function setCamera(pos, yaw, pitch) {
-  camera.pos.x = +pos[0]; camera.pos.y = +pos[1]; camera.pos.z = +pos[2];
+  const p = Array.isArray(pos) || ArrayBuffer.isView(pos) ? pos : [pos.x, pos.y, pos.z];
+  if (!(Number.isFinite(+p[0]) && Number.isFinite(+p[1]) && Number.isFinite(+p[2]))) throw new TypeError('setCamera: position must be [x, y, z] or {x, y, z} of finite numbers');
+  camera.pos.x = +p[0]; camera.pos.y = +p[1]; camera.pos.z = +p[2];
   camera.yaw = +yaw || 0;
   camera.pitch = +pitch || 0;
   return camera;

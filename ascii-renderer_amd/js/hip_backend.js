@@ -12,6 +12,9 @@
 // Beyond the reference: appState.depth (Float32Array cols*rows) and appState.ascii (Uint8Array
 // cols*rows) are filled when present, and a scene may carry `mesh` = {positions: Float32Array,
 // indices: Uint32Array, colors?: Float32Array (per triangle)} as a typed-array fast path.
+// Also beyond it: renderAsync(timeSec, appState, framebuffer?) -> token and collect(token, framebuffer?) - the
+// reference's caller already keeps one frame in flight and two framebuffers (js/main.js:243-248,364-375) around a
+// render that blocks; with these two calls several frames render and copy out while the caller works.
 import { config } from './config.js';
 import { camera as LiveCamera } from './camera.js';
 import { native, AR_OPT_PATH } from './native.js';
@@ -331,7 +334,15 @@ export class HipRasterBackend {
     // texel coordinates of tris and quads, as the path tracer's primary ray does.  Off by default, which keeps
     // frames identical to the reference's rasterizer; may be set on the instance before setScene.
     this.renderQuads = !!(opts && opts.renderQuads);
-    this._pinned = new WeakSet();  // framebuffers handed out by allocFramebuffer
+    this._pinned = new WeakSet();  // page-locked arrays handed out by allocFramebuffer / allocAsciiPlane / allocDepthPlane
+    // Frames enqueued by renderAsync and not yet collected, by staging slot, and per slot the page-locked rgba / ascii /
+    // depth planes that stand in for callers' plain arrays.  The GPU works on three frames at a time; a queue of six
+    // keeps every one of its three frame streams fed while the host prepares the next frame.
+    this._maxInFlight = Math.max(1, Math.min(16, ((opts && opts.framesInFlight) | 0) || 6));
+    this._flights = new Array(this._maxInFlight).fill(null);
+    this._staging = this._flights.map(() => ({}));
+    this._nextFlight = 0;
+    this._rampCache = { text: null, bytes: null };
   }
 
   // Uint8ClampedArray(cols*rows*4) over page-locked host memory.  render() fills such a framebuffer by
@@ -346,8 +357,8 @@ export class HipRasterBackend {
   }
 
   // Page-locked planes for the optional appState.ascii (Uint8Array) / appState.depth (Float32Array) outputs.
-  allocAsciiPlane(cols, rows) { this._ensure(); return new Uint8Array(native().allocHost(this._h, cols * rows)); }
-  allocDepthPlane(cols, rows) { this._ensure(); return new Float32Array(native().allocHost(this._h, cols * rows * 4)); }
+  allocAsciiPlane(cols, rows) { this._ensure(); const a = new Uint8Array(native().allocHost(this._h, cols * rows)); this._pinned.add(a); return a; }
+  allocDepthPlane(cols, rows) { this._ensure(); const a = new Float32Array(native().allocHost(this._h, cols * rows * 4)); this._pinned.add(a); return a; }
 
   _ensure() {
     if (this._h) return;
@@ -356,11 +367,14 @@ export class HipRasterBackend {
   }
 
   dispose() {
-    if (this._h) native().destroy(this._h);
+    if (this._h) native().destroy(this._h);   // waits for frames in flight
     this._h = null;
     this._lastTopDown = null;
     this._own = null;
     this._hasGeometry = false;
+    this._flights = new Array(this._maxInFlight).fill(null);
+    this._staging = this._flights.map(() => ({}));
+    this._nextFlight = 0;
   }
 
   setScene(scene) {
@@ -395,22 +409,32 @@ export class HipRasterBackend {
     native().setModel(this._h, m ? (m instanceof Float32Array ? m : new Float32Array(m)) : null);
   }
 
-  render(timeSec, framebuffer, appState) {
-    this._ensure();
-    const w = ((appState && appState.cols) | 0) || (config.VIRTUAL_GRID_WIDTH | 0) || 1;
-    const h = ((appState && appState.rows) | 0) || (config.VIRTUAL_GRID_HEIGHT | 0) || 1;
-    this._width = w; this._height = h;
-    if (!this._hasGeometry) return;                      // raster.js:274
+  // The per-frame uniforms: camera read live (raster.js:284-286), lights packed from the retained scene object every
+  // frame as the reference does (raster.js:307-342: a light moved in place shows in the next frame), ASCII parameters
+  // from config.
+  _uploadFrameState(w, h, appState) {
     const cam = LiveCamera
       ? { pos: LiveCamera.pos, yaw: LiveCamera.yaw, pitch: LiveCamera.pitch }
       : ((appState && appState.camera) || { pos: { x: 0, y: 0, z: 5 }, yaw: 0, pitch: 0 });
     const m = cameraMatrices(cam, w, h);
     const L = packLights(this._scene);
     const mode = modeParams();
+    const rampText = String(config.ASCII_RAMP || '@%#*+=-:. ');
+    if (this._rampCache.text !== rampText) this._rampCache = { text: rampText, bytes: rampBytes(rampText) };
     const N = native();
     N.setCamera(this._h, m.proj, m.view);
     N.setLights(this._h, L.ambient, L.dir, L.dirColor, L.plPos, L.plCol);
-    N.setAscii(this._h, rampBytes(config.ASCII_RAMP || '@%#*+=-:. '), mode.on, mode.radius, mode.thresh);
+    N.setAscii(this._h, this._rampCache.bytes, mode.on, mode.radius, mode.thresh);
+  }
+
+  render(timeSec, framebuffer, appState) {
+    this._ensure();
+    const w = ((appState && appState.cols) | 0) || (config.VIRTUAL_GRID_WIDTH | 0) || 1;
+    const h = ((appState && appState.rows) | 0) || (config.VIRTUAL_GRID_HEIGHT | 0) || 1;
+    this._width = w; this._height = h;
+    if (!this._hasGeometry) return;                      // raster.js:274
+    this._uploadFrameState(w, h, appState);
+    const N = native();
     const depth = (appState && appState.depth && appState.depth.length === w * h) ? appState.depth : null;
     const ascii = (appState && appState.ascii && appState.ascii.length === w * h) ? appState.ascii : null;
     if (framebuffer && framebuffer.length === w * h * 4 && this._pinned.has(framebuffer)) {
@@ -428,6 +452,99 @@ export class HipRasterBackend {
     if (args && args.framebuffer && args.appState) return this.render(args.time || 0, args.framebuffer, args.appState);
     return undefined;
   }
+
+  // render() split in two, for callers that keep frames in flight (the reference's own loop does: kickGPU's
+  // gpuInFlight guard and the fbA / fbB pair, js/main.js:243-248,364-375).  renderAsync reads the camera, uploads the
+  // frame's uniforms, enqueues the frame and its copies to the host, and returns a token without waiting; collect
+  // waits for that frame and delivers it.  Up to framesInFlight frames (constructor option, default 6) may be
+  // outstanding; one more renderAsync throws.
+  //   framebuffer  a page-locked array from allocFramebuffer: the GPU writes it directly (keep it untouched until
+  //                collect); undefined: the image is staged in the backend's own page-locked memory and copied into
+  //                the array given to collect; null: no RGBA read-back at all.
+  //   appState.ascii / appState.depth: as for render(); page-locked planes (allocAsciiPlane / allocDepthPlane) are
+  //                written directly, plain arrays are filled at collect.
+  // Returns null when there is nothing to draw (raster.js:274); collect(null) is a no-op returning false.
+  renderAsync(timeSec, appState, framebuffer) {
+    this._ensure();
+    const w = ((appState && appState.cols) | 0) || (config.VIRTUAL_GRID_WIDTH | 0) || 1;
+    const h = ((appState && appState.rows) | 0) || (config.VIRTUAL_GRID_HEIGHT | 0) || 1;
+    this._width = w; this._height = h;
+    if (!this._hasGeometry) return null;
+    const slot = this._nextFlight;
+    if (this._flights[slot]) throw new Error('renderAsync: ' + this._maxInFlight + ' frames are in flight; collect the oldest first');
+    this._uploadFrameState(w, h, appState);
+    const N = native(), S = this._staging[slot];
+    const staged = (key, Type, length, bytes) => {
+      if (!S[key] || S[key].length !== length) S[key] = new Type(N.allocHost(this._h, bytes));
+      return S[key];
+    };
+    const flight = { slot, w, h, rgba: null, rgbaStaged: false, ascii: null, asciiOut: null, depth: null, depthOut: null, ticket: 0 };
+    if (framebuffer === undefined) { flight.rgba = staged('rgba', Uint8Array, w * h * 4, w * h * 4); flight.rgbaStaged = true; }
+    else if (framebuffer !== null) {
+      if (framebuffer.length !== w * h * 4 || !this._pinned.has(framebuffer)) throw new Error('renderAsync: the framebuffer must come from allocFramebuffer(cols, rows) of this backend (or be undefined / null)');
+      flight.rgba = framebuffer;
+    }
+    const wantAscii = appState && appState.ascii && appState.ascii.length === w * h ? appState.ascii : null;
+    if (wantAscii) {
+      if (this._pinned.has(wantAscii)) flight.ascii = wantAscii;
+      else { flight.ascii = staged('ascii', Uint8Array, w * h, w * h); flight.asciiOut = wantAscii; }
+    }
+    const wantDepth = appState && appState.depth && appState.depth.length === w * h ? appState.depth : null;
+    if (wantDepth) {
+      if (this._pinned.has(wantDepth)) flight.depth = wantDepth;
+      else { flight.depth = staged('depth', Float32Array, w * h, w * h * 4); flight.depthOut = wantDepth; }
+    }
+    N.renderAsync(this._h, w, h);
+    flight.ticket = N.readAsync(this._h, w, h, flight.rgba, flight.depth, flight.ascii, null);
+    this._flights[slot] = flight;
+    this._nextFlight = (slot + 1) % this._flights.length;
+    return flight;
+  }
+
+  // Waits for the frame behind `token` and hands it over: a staged image is copied into `framebuffer` (when its length
+  // matches, as render() does), staged ascii / depth planes into the arrays appState named.  True when a frame was
+  // delivered.  Tokens are collected in the order they were issued.
+  collect(token, framebuffer) {
+    if (!token) return false;
+    if (this._flights[token.slot] !== token) throw new Error('collect: unknown or already collected token');
+    native().wait(this._h, token.ticket);
+    this._flights[token.slot] = null;
+    if (token.rgba) {
+      this._lastTopDown = token.rgba;
+      if (token.rgbaStaged && framebuffer && framebuffer.length === token.rgba.length) framebuffer.set(token.rgba);
+    }
+    if (token.asciiOut) token.asciiOut.set(token.ascii);
+    if (token.depthOut) token.depthOut.set(token.depth);
+    return true;
+  }
+
+  // True when collect(token) would not wait.
+  ready(token) { return !token || native().poll(this._h, token.ticket); }
+
+  // Per-kernel GPU time (HIP events on the frame streams): profile(true) starts it, kernelStats() returns
+  // { kernel: { launches, ms } } for the launches since the last call, waiting for the frames in flight.
+  profile(on) { this._ensure(); native().setProfiling(this._h, !!on); }
+  kernelStats() { this._ensure(); return native().kernelStats(this._h); }
+
+  // Multi-GPU and interop plumbing, as the C ABI offers it (addresses are BigInt): restrict frames to a strip of rows,
+  // run them on a caller's HIP stream, store the ASCII plane in a caller's device buffer, hand outputs over in stream
+  // order, and read the planes of the last frame on demand.
+  setStrip(row0, row1) { this._ensure(); native().setStrip(this._h, row0 | 0, row1 | 0); }
+  setStream(stream) { this._ensure(); native().setStream(this._h, stream || null); }
+  setAsciiTarget(address, firstRow) { this._ensure(); native().setAsciiTarget(this._h, address || null, firstRow | 0); }
+  streamWaitFrame(stream) { this._ensure(); native().streamWaitFrame(this._h, stream); }
+  frameWaitStream(stream) { this._ensure(); native().frameWaitStream(this._h, stream); }
+  deviceBuffer(which) { this._ensure(); return native().deviceBuffer(this._h, { rgba: 0, depth: 1, ascii: 2 }[which]); }
+  sync() { this._ensure(); native().sync(this._h); }
+  setIdOutput(on) { this._ensure(); native().setIdOutput(this._h, !!on); }
+  // Planes of the most recent frame (any may be null); ids needs setIdOutput(true) before that frame.
+  read(planes) {
+    this._ensure();
+    const p = planes || {};
+    native().read(this._h, this._width, this._height, p.rgba || null, p.depth || null, p.ascii || null, p.ids || null);
+  }
+  // Text colours of the most recent frame (packed r << 16 | g << 8 | b, see AsciiPass.colorsFromBuffer).
+  readColors(out, steps, grayscale) { this._ensure(); native().readColors(this._h, this._width, this._height, steps | 0, !!grayscale, out); return out; }
 
   // The reference keeps the bottom-up readPixels image and flips on request (raster.js:366-375);
   // this backend keeps the top-down image, so flipY = true is the plain copy.

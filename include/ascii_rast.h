@@ -131,6 +131,21 @@ int ar_render_async(ar_ctx *ctx, int cols, int rows);
 int ar_sync(ar_ctx *ctx);
 int ar_read(ar_ctx *ctx, uint8_t *rgba, float *depth, uint8_t *ascii, uint32_t *ids);
 
+/* Read-back that does not wait: queues the device->host copies of the most recently enqueued frame's planes (each
+ * pointer may be NULL, as for ar_read) behind that frame, on the stream it runs on, and returns at once with a
+ * ticket; ar_wait blocks until the frame and its copies are complete, ar_poll asks without blocking (1 complete,
+ * 0 still running).  The counterpart in the reference is its caller's frame in flight: js/main.js holds two
+ * framebuffers and a gpuInFlight guard (main.js:243-248,364-375) around a render that in fact blocks in readPixels
+ * (raster.js:358-361); here up to three frames (AR_OPT_OVERLAP) render and copy while the caller does other work.
+ * The host buffers must stay valid until the ticket has been waited for and should be page-locked (ar_host_alloc):
+ * into pageable memory the call itself waits for the copy.  The next frame on the same stream - the third
+ * ar_render_async after this one while frames overlap, the next one otherwise - starts after the copies, so the
+ * device buffers are never overwritten under them.  A ticket stays valid until the context is destroyed; waiting
+ * for an old one is harmless.  All pointers NULL gives a ticket for the frame alone. */
+int ar_read_async(ar_ctx *ctx, uint8_t *rgba, float *depth, uint8_t *ascii, uint32_t *ids, uint64_t *ticket);
+int ar_wait(ar_ctx *ctx, uint64_t ticket);
+int ar_poll(ar_ctx *ctx, uint64_t ticket);
+
 /* Device addresses of the output buffers of the most recently enqueued frame: which = 0 rgba, 1 depth,
  * 2 ascii.  NULL before the first render.  While frames overlap (AR_OPT_OVERLAP) consecutive frames write
  * different sets of buffers in rotation, so ask again after each ar_render_async; with AR_OPT_OVERLAP 0, with

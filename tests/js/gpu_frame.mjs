@@ -154,6 +154,70 @@ const dump = (name, ta) => fs.writeFileSync(path.join(outDir, name), Buffer.from
     sp.dispose();
   }
 
+  // frames in flight: a burst of five cameras through renderAsync / collect, three outstanding at a time, every way
+  // of receiving the planes (staged and copied at collect, written directly into page-locked arrays, no image at all)
+  {
+    const hb = await import(path.join(JS, 'hip_backend.js'));
+    const fl = new hb.HipRasterBackend({ framesInFlight: 3 });
+    fl.setScene(sceneApi.meshScene(ico, { lights }));
+    const cols = 640, rows = 360, n = cols * rows;
+    meta.burst = { cols, rows, pixelAspect: config.PATH_TRACER.PIXEL_ASPECT, cams: [] };
+    fl.profile(true);
+    fl.kernelStats();
+    const pending = [], pinnedFb = [fl.allocFramebuffer(cols, rows), fl.allocFramebuffer(cols, rows)];
+    const deliver = () => {
+      const p = pending.shift();
+      if (!fl.collect(p.token, p.fb)) throw new Error('collect should deliver a frame');
+      if (p.fb) dump('burst' + p.k + '.rgba', p.fb);
+      dump('burst' + p.k + '.ascii', p.state.ascii);
+      if (p.state.depth) dump('burst' + p.k + '.depth', p.state.depth);
+    };
+    for (let k = 0; k < 5; k++) {
+      const a = 0.35 + 0.5 * k, e = [3 * Math.cos(a), 0.6 + 0.2 * k, 3 * Math.sin(a)], len = Math.hypot(e[0], e[1], e[2]);
+      const c = { pos: e, yaw: Math.atan2(-e[2], -e[0]), pitch: Math.asin(-e[1] / len) };
+      meta.burst.cams.push(c);
+      setCamera(c.pos, c.yaw, c.pitch);
+      if (pending.length === 3) {
+        let refused = false;
+        if (k === 3) { try { fl.renderAsync(0, { cols, rows }); } catch (err) { refused = /in flight/.test(String(err.message)); } if (!refused) throw new Error('a fourth frame in flight must be refused'); }
+        deliver();
+      }
+      let token, fb, state;
+      if (k % 3 === 0) {          // staged image, plain planes filled at collect
+        state = { cols, rows, ascii: new Uint8Array(n), depth: new Float32Array(n) }; fb = new Uint8ClampedArray(n * 4);
+        token = fl.renderAsync(k / 60, state);
+      } else if (k % 3 === 1) {   // everything page-locked and written by the GPU
+        state = { cols, rows, ascii: fl.allocAsciiPlane(cols, rows), depth: fl.allocDepthPlane(cols, rows) }; fb = pinnedFb[k === 1 ? 0 : 1];
+        token = fl.renderAsync(k / 60, state, fb);
+      } else {                    // codes only
+        state = { cols, rows, ascii: new Uint8Array(n) }; fb = null;
+        token = fl.renderAsync(k / 60, state, null);
+      }
+      if (typeof fl.ready(token) !== 'boolean') throw new Error('ready() should answer true or false');
+      pending.push({ k, token, fb, state });
+    }
+    while (pending.length) deliver();
+    if (fl.collect(null) !== false) throw new Error('collect(null) is a no-op');
+    meta.burst.kernels = fl.kernelStats();
+    fl.profile(false);
+    // the rest of the C ABI as the addon binds it: planes of the last frame on demand, ids, colours, addresses
+    fl.setIdOutput(true);
+    const t = fl.renderAsync(0, { cols, rows }, null);
+    fl.collect(t);
+    const ids = new Uint32Array(n), asc = new Uint8Array(n), colors = new Uint32Array(n);
+    fl.read({ ids, ascii: asc });
+    fl.readColors(colors, 0, false);
+    dump('burst_last.ids', ids); dump('burst_last.ascii', asc); dump('burst_last.colors', colors);
+    if (typeof fl.deviceBuffer('ascii') !== 'bigint' || fl.deviceBuffer('ascii') === 0n) throw new Error('deviceBuffer should be a device address');
+    fl.setStrip(100, 200);
+    const strip = new Uint8Array(n);
+    fl.collect(fl.renderAsync(0, { cols, rows, ascii: strip }, null));
+    dump('burst_strip.ascii', strip);
+    fl.setStrip(0, 0);
+    fl.sync();
+    fl.dispose();
+  }
+
   // the ray backend under the reference's names: router -> HipRaytraceBackend -> ar_rt_set_scene / ar_rt_render
   {
     const rtRef = JSON.parse(fs.readFileSync(path.join(here, '..', 'golden', 'ref_raytrace_uniforms.json'), 'utf8'));

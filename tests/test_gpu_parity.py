@@ -463,6 +463,53 @@ def test_back_to_back_frames_overlap_without_interfering(pkg, oracle):
         r.close()
 
 
+def test_read_back_without_waiting_every_frame_of_a_burst(pkg, oracle):
+    """ar_read_async / ar_wait / ar_poll: each frame of a burst is copied to page-locked host memory behind its own
+    kernels while the next frames are already enqueued; every frame must arrive intact, overlapped or not, and the
+    buffer sets must not be overwritten under a copy (nine frames over three sets)."""
+    r = pkg.Renderer(0)
+    try:
+        cols, rows = 333, 127
+        sc = pkg.scenes.random_scene(60_000, cols, rows, mesh_grid=(cols, rows))
+        pkg.scenes.upload(r, sc)
+        cams = [{"pos": (0.0, 0.0, 0.0), "yaw": 0.03 * k, "pitch": -0.01 * k} for k in range(9)]
+        expect = []
+        for cam in cams:
+            proj, view = pkg.host.camera_matrices(cam, cols, rows, 1.0)
+            rgba, depth, ids = oracle.render(sc["vbo"], sc["idx"], proj, view, sc["lights"], cols, rows)
+            expect.append((proj, view, rgba, depth, ids, oracle.quantize(rgba, cols, rows, pkg.scenes.DEFAULT_RAMP, 1, 2, 12)))
+        with pytest.raises(pkg.AsciiRastError):
+            r.wait(5)                                      # a ticket nobody issued
+        r.set_id_output(True)
+        for overlap in (1, 0):
+            r.set_option("overlap", overlap)
+            bufs = [(r.host_array((rows, cols, 4), np.uint8), r.host_array((rows, cols), np.float32),
+                     r.host_array((rows, cols), np.uint8), r.host_array((rows, cols), np.uint32)) for _ in cams]
+            tickets = []
+            for k, (proj, view, *_rest) in enumerate(expect):
+                r.set_camera(proj, view)
+                r.render_async(cols, rows)
+                tickets.append(r.read_async(*bufs[k]))
+            assert len(set(tickets)) == len(tickets)
+            for k in (4, 0, 8, 1, 2, 3, 5, 6, 7):            # any order, old tickets included
+                r.wait(tickets[k])
+                assert r.poll(tickets[k]) is True
+                _p, _v, rgba, depth, ids, asc = expect[k]
+                tag = "overlap %d frame %d" % (overlap, k)
+                assert np.array_equal(bufs[k][0], rgba), tag
+                assert np.array_equal(bufs[k][1].view(np.uint32), depth.view(np.uint32)), tag
+                assert np.array_equal(bufs[k][2], asc), tag
+                assert np.array_equal(bufs[k][3], ids), tag
+            # a ticket for the frame alone (no copies), then the blocking read of the same frame
+            r.render_async(cols, rows)
+            t = r.read_async()
+            r.wait(t)
+            out = r.read(want_ids=True)
+            assert np.array_equal(out["ascii"], expect[-1][5]) and np.array_equal(out["ids"], expect[-1][4])
+    finally:
+        r.close()
+
+
 def test_callers_stream_ascii_target_and_stream_handover(pkg, oracle):
     """The calls the multi-GPU loop is built from: frames on the caller's stream writing their ASCII strip
     into the caller's buffer (ar_set_stream, ar_set_ascii_target), and the stream-ordered hand-over

@@ -102,6 +102,33 @@ def test_node_harness_frames_match_oracle(pkg, oracle, tmp_path, rt_uniforms_of)
                               oracle.quantize(rgba, spin["cols"], spin["rows"], ramp, 1, 2, 12)), k
         assert np.count_nonzero(depth < 1.0) > 100
 
+    # frames in flight (renderAsync / collect): five cameras, three outstanding at a time, each against the oracle
+    b = meta["burst"]
+    cols, rows = b["cols"], b["rows"]
+    (P, I), scene = meshes["ico"]
+    vbo, idx = pkg.host.mesh_to_vbo(P, I)
+    lights = pkg.host.pack_lights(scene)
+    assert len(b["cams"]) == 5
+    for k, cam in enumerate(b["cams"]):
+        proj, view = pkg.host.camera_matrices(cam, cols, rows, b["pixelAspect"])
+        rgba, depth, ids = oracle.render(vbo, idx, proj, view, lights, cols, rows)
+        asc = oracle.quantize(rgba, cols, rows, ramp, 1, 2, 12)
+        assert np.count_nonzero(depth < 1.0) > 1000
+        assert np.array_equal(np.fromfile(tmp_path / ("burst%d.ascii" % k), dtype=np.uint8).reshape(rows, cols), asc), k
+        if k % 3 != 2:
+            assert np.array_equal(np.fromfile(tmp_path / ("burst%d.rgba" % k), dtype=np.uint8).reshape(rows, cols, 4), rgba), k
+            assert np.array_equal(np.fromfile(tmp_path / ("burst%d.depth" % k), dtype=np.float32).view(np.uint32).reshape(rows, cols),
+                                  depth.view(np.uint32)), k
+    assert {"k_setup", "k_fill", "k_tile", "k_ascii"} <= set(b["kernels"]), b["kernels"]
+    assert all(b["kernels"][k]["launches"] == 5 and b["kernels"][k]["ms"] > 0 for k in ("k_setup", "k_fill", "k_tile", "k_ascii")), b["kernels"]
+    # last camera again: ids, codes and colours read on demand; then rows 100..199 only
+    assert np.array_equal(np.fromfile(tmp_path / "burst_last.ids", dtype=np.uint32).reshape(rows, cols), ids)
+    assert np.array_equal(np.fromfile(tmp_path / "burst_last.ascii", dtype=np.uint8).reshape(rows, cols), asc)
+    assert np.array_equal(np.fromfile(tmp_path / "burst_last.colors", dtype=np.uint32).reshape(rows, cols),
+                          oracle.quantize_colors(rgba, cols, rows, len(ramp)))
+    strip = np.fromfile(tmp_path / "burst_strip.ascii", dtype=np.uint8).reshape(rows, cols)
+    assert np.array_equal(strip[100:200], asc[100:200])
+
     # the ray backend through the router: same image as the oracle fed with the reference's recorded uniforms
     rtm = meta["raytrace"]
     with open(os.path.join(ROOT, "tests", "golden", "ref_raytrace_uniforms.json")) as fh:
