@@ -395,6 +395,11 @@ class Renderer:
         self._check(self._L.ar_quantize(self._h, rgba.ctypes.data_as(_u8p), int(cols), int(rows), out.ctypes.data_as(_u8p)))
         return out
 
+    def quantize_into(self, rgba, cols, rows, out):
+        """quantize() with caller-owned arrays (uint8, C-contiguous): no conversions or allocations on the way."""
+        self._check(self._L.ar_quantize(self._h, rgba.ctypes.data_as(_u8p), int(cols), int(rows), out.ctypes.data_as(_u8p)))
+        return out
+
     def quantize_static(self, rgba, cols, rows):
         """quantize() through the library's fixed staging array: no device allocation on the way."""
         rgba = np.ascontiguousarray(np.asarray(rgba, dtype=np.uint8).reshape(-1))

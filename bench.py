@@ -321,6 +321,28 @@ def main(argv=None):
             "pinned_ascii_only": readback(None, R.host_array((args.rows, args.cols), np.uint8)),
         }
 
+    if not args.no_extras and rank == 0 and not gather:
+        # the RGBA -> ASCII entry point (AsciiPass.drawFromBuffer's index half) beside the reference's own CPU twin of it:
+        # host grid in, host codes out, blocking - what a caller of ar_quantize sees
+        rng = np.random.default_rng(12345)
+
+        def quantize_rate(cols, rows, pinned, n=20):
+            if pinned:
+                grid = R.host_array((rows, cols, 4), np.uint8)
+                grid[...] = rng.integers(0, 256, size=(rows, cols, 4), dtype=np.uint8)
+                out = R.host_array((rows, cols), np.uint8)
+            else:
+                grid = rng.integers(0, 256, size=(rows, cols, 4), dtype=np.uint8)
+                out = np.zeros((rows, cols), np.uint8)
+            grid[..., 3] = 255
+            R.quantize_into(grid, cols, rows, out)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                R.quantize_into(grid, cols, rows, out)
+            return n / (time.perf_counter() - t0)
+        extras["quantize_fps"] = {"1080p_pageable": quantize_rate(1920, 1080, False), "1080p_pinned": quantize_rate(1920, 1080, True),
+                                  "4k_pageable": quantize_rate(3840, 2160, False), "4k_pinned": quantize_rate(3840, 2160, True)}
+
     if rank == 0:
         cells = args.cols * (row1 - row0)
         entries = counters["bin_records"]
@@ -344,15 +366,26 @@ def main(argv=None):
         dom = max(kern_serial, key=lambda k: kern_serial[k])
         dom_s = kern_serial[dom] * 1e-6
         achieved = per_launch_bytes.get(dom, 0) / dom_s / 1e9
+        # Counter figures (rocprofv3 --pmc passes cannot run inside this process) come from profiles/traffic.json, which
+        # carries a fingerprint of the kernel sources it was taken on: when the sources have changed since, the line
+        # says so and carries none of them.
         traffic = requests = None
-        valu, tj = {}, {}
+        valu, tj, busy = {}, {}, {}
+        traffic_stale = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
+            here = importlib.import_module("ascii-renderer_amd.provenance").csrc_hash()
+            traffic_stale = tj.get("_csrc_hash") != here
+            if traffic_stale:
+                tj = {}
             traffic = tj.get(dom)
             requests = tj.get("_read_requests", {}).get(dom)
             valu = tj.get("_valu_instructions", {})
+            busy = tj.get("_busy", {})
+        clock_hz = busy.get("clock_ghz_under_load", 0.0) * 1e9 or None     # engine clock under load, from GRBM_GUI_ACTIVE
+        kb = busy.get("kernels", {})
         # bytes of the layout the per-frame kernels actually read and write: position planes 36 B/triangle, one 64-byte
         # triangle record and one 4-byte entry (written once, read once) per binned (sub-triangle, bin) pair, RGBA8 +
         # depth + ramp index written and ramp index read + ASCII written per cell
@@ -382,12 +415,19 @@ def main(argv=None):
                          "read_requests": requests,
                          "read_request_rate_G_per_s": (requests / dom_s / 1e9) if requests else None,
                          "scattered_line_ceiling_G_per_s": SCATTERED_LINES_G_PER_S,
-                         # what the kernel is bound by in fact: vector-ALU issue.  Wave instructions per launch (PMC) x 4
-                         # cycles over the SIMD-cycles of the live duration at the peak clock
+                         # what the kernel is bound by in fact: vector-ALU issue.  From counters: SQ_ACTIVE_INST_VALU (units of
+                         # four cycles of one SIMD) over the SIMD-cycles of the live duration at the clock measured under load
+                         # (GRBM_GUI_ACTIVE against kernel durations); and over the cycles its compute units were busy at all
                          "valu_instructions": valu.get(dom),
-                         "valu_busy_frac": (valu[dom] * 4.0 / (N_SIMDS * PEAK_CLOCK_HZ * dom_s)) if (valu.get(dom) and not gather) else None},
+                         "clock_ghz_under_load": (clock_hz / 1e9) if clock_hz else None,
+                         "valu_busy_frac": (kb[dom]["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * clock_hz * dom_s))
+                                           if (kb.get(dom) and clock_hz and not gather) else None,
+                         "valu_busy_frac_while_cu_busy": (kb[dom]["SQ_ACTIVE_INST_VALU"] * 4.0 / (4.0 * kb[dom]["SQ_BUSY_CU_CYCLES"]))
+                                                         if (kb.get(dom) and not gather) else None},
+            "traffic_stale": traffic_stale,
             # the same for the whole frame at the measured frame rate (kernels of three frames share the chip)
-            "frame_valu_busy_frac": (sum(valu.get(k, 0) for k in kern_serial) * 4.0 * fps / (N_SIMDS * PEAK_CLOCK_HZ)) if (valu and not gather) else None,  # (counters are of whole frames on one GPU)
+            "frame_valu_busy_frac": (sum(kb[k]["SQ_ACTIVE_INST_VALU"] for k in kern_serial if k in kb) * 4.0 * fps / (N_SIMDS * clock_hz))
+                                    if (kb and clock_hz and not gather) else None,  # (counters are of whole frames on one GPU)
             "gather_verified": gather_ok,
             "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
             "kernels_avg_us_serial": {k: round(v, 2) for k, v in kern_serial.items()},
@@ -395,6 +435,12 @@ def main(argv=None):
         line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ar, sc)
+            # the one stage of this path the reference itself runs on the CPU, as measured on the reference's code in the
+            # build container (quoted; the reference is never shipped to the GPU box)
+            line["cpu_baseline"]["reference_stage"] = {
+                "fn": "compositeAndQuantize (js/renderer.js:21-99)", "ms_1080p": 219, "ms_4k": 975,
+                "where": "reference code imported under Node 12, 1 core, in the build container; random RGBA grid",
+                "gpu_twin": "ar_quantize, see quantize_fps"}
         print(json.dumps(line), file=result_out, flush=True)
     R.close()
     if gather:
