@@ -18,7 +18,7 @@ EXPORTS = [
     "ar_set_ascii_target", "ar_quantize", "ar_quantize_colors", "ar_read_colors", "ar_present", "ar_set_profiling", "ar_kernel_stats",
     "ar_frame_counters", "ar_set_option", "ar_set_mesh_uv", "ar_set_texture", "ar_set_mesh_indexed", "ar_read_mesh",
     "ar_rt_set_scene", "ar_rt_render", "ar_rt_render_async", "ar_quantize_static", "ar_set_model",
-    "ar_read_async", "ar_wait", "ar_poll",
+    "ar_read_async", "ar_wait", "ar_poll", "ar_update_positions",
 ]
 _lib = None
 
@@ -74,6 +74,8 @@ def load_library():
     L.ar_rt_render_async.argtypes = [vp, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float]
     L.ar_set_mesh_indexed.argtypes = [vp, _fp, ctypes.c_uint32, _u32p, ctypes.c_uint32, _fp]
     L.ar_read_mesh.argtypes = [vp, _fp, _u32p, _u32p, _u32p]
+    L.ar_update_positions.argtypes = [vp, _fp, ctypes.c_uint32, ctypes.c_int, ctypes.c_int]
+    L.ar_update_positions.restype = ctypes.c_int
     L.ar_set_mesh_uv.argtypes = [vp, ctypes.POINTER(ctypes.c_uint16), ctypes.c_uint32]
     L.ar_set_texture.argtypes = [vp, _u8p, ctypes.c_int, ctypes.c_int]
     L.ar_set_camera.argtypes = [vp, _fp, _fp]
@@ -174,6 +176,14 @@ class Renderer:
             if col.size != ind.size:
                 raise ValueError("colors must hold 3 floats per triangle")
         self._check(self._L.ar_set_mesh_indexed(self._h, pp, pos.size // 3, ind.ctypes.data_as(_u32p), ind.size // 3, cp))
+
+    def update_positions(self, data, flat_normals=False, resort=False):
+        """New vertex data for the current mesh in place: data is [V, 9] (whole vertices) or [V, 3] (positions only)."""
+        a = np.ascontiguousarray(data, dtype=np.float32)
+        if a.ndim != 2 or a.shape[1] not in (3, 9):
+            raise ValueError("data must be [n_verts, 3] or [n_verts, 9]")
+        self._check(self._L.ar_update_positions(self._h, a.ctypes.data_as(_fp), a.shape[0], a.shape[1],
+                                                (1 if flat_normals else 0) | (2 if resort else 0)))
 
     def read_mesh(self):
         """(vbo float32 [V, 9], idx uint32 [3 T]) of the current mesh as held on the GPU."""

@@ -96,6 +96,10 @@ ar_ctx *ar_create(int device_id) {
     ctx->fstream[0] = ctx->own_stream;
     for (int k = 1; ok && k < kSets; k++) ok = hipStreamCreateWithFlags(&ctx->fstream[k], hipStreamNonBlocking) == hipSuccess;
     for (int k = 0; ok && k <= kSets; k++) ok = hipEventCreateWithFlags(&ctx->ev_out[k], hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; ok && k < kSets; k++) ok = hipEventCreateWithFlags(&ctx->ev_upd[k], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->ev_staged, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&ctx->ev_taken, hipEventDisableTiming) == hipSuccess &&
+         hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking) == hipSuccess;
     for (int k = 0; ok && k <= kSets; k++)
         for (int j = 0; ok && j < kTicketRing; j++) ok = hipEventCreateWithFlags(&ctx->ev_done[k][j], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
@@ -146,6 +150,12 @@ void ar_destroy(ar_ctx *ctx) {
             if (ctx->ev_done[k][j]) (void)hipEventDestroy(ctx->ev_done[k][j]);
     }
     if (ctx->ev_ext) (void)hipEventDestroy(ctx->ev_ext);
+    for (int k = 0; k < kSets; k++)
+        if (ctx->ev_upd[k]) (void)hipEventDestroy(ctx->ev_upd[k]);
+    if (ctx->ev_staged) (void)hipEventDestroy(ctx->ev_staged);
+    if (ctx->ev_taken) (void)hipEventDestroy(ctx->ev_taken);
+    if (ctx->up_stream) { (void)hipStreamSynchronize(ctx->up_stream); (void)hipStreamDestroy(ctx->up_stream); }
+    (void)hipFree(ctx->d_upd);
     for (int k = 1; k < kSets; k++)
         if (ctx->fstream[k]) (void)hipStreamDestroy(ctx->fstream[k]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -197,6 +207,78 @@ int ar_set_mesh_indexed(ar_ctx *ctx, const float *positions, uint32_t n_verts, c
     (void)hipFree(d_pos); (void)hipFree(d_ind); (void)hipFree(d_col);
     if (rc) return rc;
     return finish_mesh(ctx, 3u * n_tris, n_tris);
+}
+
+int ar_update_positions(ar_ctx *ctx, const float *data, uint32_t n_verts, int floats_per_vertex, int flags) {
+    if (!ctx) return AR_E_ARG;
+    if (!data || (floats_per_vertex != 3 && floats_per_vertex != 9) || (flags & ~(AR_UPDATE_FLAT_NORMALS | AR_UPDATE_RESORT)))
+        return fail(ctx, AR_E_ARG, "ar_update_positions: bad arguments (%d floats per vertex, flags %d)", floats_per_vertex, flags);
+    if (!ctx->n_tris || !ctx->d_vbo) return fail(ctx, AR_E_STATE, "ar_update_positions: no mesh to update");
+    if (n_verts != ctx->n_verts) return fail(ctx, AR_E_ARG, "ar_update_positions: %u vertices for a mesh of %u", n_verts, ctx->n_verts);
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t n_tris = ctx->n_tris;
+    hipStream_t s = ctx->own_stream;  // == fstream[0]
+    const size_t n_floats = size_t(n_verts) * size_t(floats_per_vertex);
+    if (ctx->upd_floats < n_floats) {  // (first update of this size only)
+        int rc = sync_streams(ctx);
+        if (rc) return rc;
+        (void)hipFree(ctx->d_upd);
+        ctx->d_upd = nullptr; ctx->upd_floats = 0;
+        AR_HIP(ctx, hipMalloc(&ctx->d_upd, n_floats * sizeof(float)));
+        ctx->upd_floats = n_floats;
+    }
+    // The caller's data goes to a staging buffer on a stream of its own, and the host waits for that copy alone (so
+    // `data` is free again on return) - behind the previous update's use of the buffer, not behind any frame.
+    if (ctx->upd_pending) AR_HIP(ctx, hipStreamWaitEvent(ctx->up_stream, ctx->ev_taken, 0));
+    AR_HIP(ctx, hipMemcpyAsync(ctx->d_upd, data, n_floats * sizeof(float), hipMemcpyHostToDevice, ctx->up_stream));
+    AR_HIP(ctx, hipEventRecord(ctx->ev_staged, ctx->up_stream));
+    AR_HIP(ctx, hipStreamSynchronize(ctx->up_stream));
+    // frames in flight read the streams this call rewrites: the update waits for them on the GPU, not on the host
+    for (int k = 1; k < kSets; k++) {
+        AR_HIP(ctx, hipEventRecord(ctx->ev_upd[k], ctx->fstream[k]));
+        AR_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_upd[k], 0));
+    }
+    if (ctx->stream != ctx->own_stream) {
+        AR_HIP(ctx, hipEventRecord(ctx->ev_upd[0], ctx->stream));
+        AR_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_upd[0], 0));
+    }
+    AR_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_staged, 0));
+    if (floats_per_vertex == 9) AR_HIP(ctx, hipMemcpyAsync(ctx->d_vbo, ctx->d_upd, n_floats * sizeof(float), hipMemcpyDeviceToDevice, s));
+    else k_put_positions<<<(n_verts + 255) / 256, 256, 0, s>>>(ctx->d_upd, n_verts, ctx->d_vbo);
+    AR_HIP(ctx, hipEventRecord(ctx->ev_taken, s));
+    ctx->upd_pending = true;
+    if (flags & AR_UPDATE_FLAT_NORMALS) k_flat_normals<<<(n_tris + 255) / 256, 256, 0, s>>>(ctx->d_vbo, ctx->d_idx, n_verts, n_tris);
+    AR_HIP(ctx, hipGetLastError());
+    if (flags & AR_UPDATE_RESORT) {
+        // a new spatial order: what ar_set_mesh does after its upload (allocates, and waits for the GPU)
+        int rc = sync_streams(ctx);
+        if (rc) return rc;
+        const bool had_uv = ctx->d_triuv != nullptr;
+        (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr); (void)hipFree(ctx->d_tri); (void)hipFree(ctx->d_tri_t);
+        (void)hipFree(ctx->d_perm); (void)hipFree(ctx->d_box);
+        ctx->d_tripos = nullptr; ctx->d_triattr = nullptr; ctx->d_tri = nullptr; ctx->d_tri_t = nullptr; ctx->d_perm = nullptr; ctx->d_box = nullptr;
+        rc = finish_mesh(ctx, n_verts, n_tris);
+        if (rc) return rc;
+        if (had_uv) {
+            k_uvflags<<<(n_tris + 255) / 256, 256, 0, s>>>(ctx->d_triuv, ctx->d_perm, n_tris, ctx->d_tri, ctx->d_tri_t);
+            AR_HIP(ctx, hipGetLastError());
+            AR_HIP(ctx, hipStreamSynchronize(s));
+        }
+        return 0;
+    }
+    // the derived streams, rewritten in the spatial order chosen at upload (slot -> triangle stays as it is)
+    const unsigned blocks = unsigned((size_t(n_tris) + 255) / 256);
+    const bool attr = floats_per_vertex == 9 || (flags & AR_UPDATE_FLAT_NORMALS);  // normals or colours may have changed too
+    if (attr) k_tristream<true><<<blocks, 256, 0, s>>>(ctx->d_vbo, ctx->d_idx, ctx->d_perm, n_verts, n_tris, ctx->tripos_stride,
+                                                      ctx->d_tripos, ctx->d_triattr, ctx->d_tri, ctx->d_tri_t, ctx->d_box);
+    else k_tristream<false><<<blocks, 256, 0, s>>>(ctx->d_vbo, ctx->d_idx, ctx->d_perm, n_verts, n_tris, ctx->tripos_stride,
+                                                  ctx->d_tripos, ctx->d_triattr, ctx->d_tri, ctx->d_tri_t, ctx->d_box);
+    if (attr && ctx->d_triuv) k_uvflags<<<(n_tris + 255) / 256, 256, 0, s>>>(ctx->d_triuv, ctx->d_perm, n_tris, ctx->d_tri, ctx->d_tri_t);
+    AR_HIP(ctx, hipGetLastError());
+    AR_HIP(ctx, hipEventRecord(ctx->ev_upd[0], s));
+    for (int k = 1; k < kSets; k++) AR_HIP(ctx, hipStreamWaitEvent(ctx->fstream[k], ctx->ev_upd[0], 0));
+    if (ctx->stream != ctx->own_stream) AR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_upd[0], 0));
+    return 0;
 }
 
 int ar_read_mesh(ar_ctx *ctx, float *vbo9, uint32_t *idx, uint32_t *n_verts, uint32_t *n_tris) {

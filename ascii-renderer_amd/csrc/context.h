@@ -68,6 +68,12 @@ struct ar_ctx {
     void *d_rt = nullptr;            // ray backend: the scene arrays of ar_rt_set_scene in one allocation
     RtScene rt_scene = {};           // counts and device pointers into d_rt
     bool rt_has_scene = false;
+    float *d_upd = nullptr;          // staging for ar_update_positions, grown on demand
+    size_t upd_floats = 0;
+    hipStream_t up_stream = nullptr; // its upload stream: the host waits for the copy into the staging buffer, never for frames
+    hipEvent_t ev_upd[kSets] = {};   // ar_update_positions: frames in flight done / update done
+    hipEvent_t ev_staged = nullptr, ev_taken = nullptr;  // staging buffer filled / consumed by the previous update
+    bool upd_pending = false;        // ev_taken has been recorded
     uint4 *d_triuv = nullptr;        // n_tris texel-coordinate rows (ar_set_mesh_uv), else null
     uint32_t *d_atlas = nullptr;     // atlas texels (ar_set_texture), else null
     int atlas_w = 0, atlas_h = 0;
@@ -237,7 +243,7 @@ int finish_mesh(ar_ctx *ctx, uint32_t n_verts, uint32_t n_tris) {
         AR_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, d_code, d_code_sorted, d_order, ctx->d_perm, int(n_tris), 0, 30, ctx->stream));
         AR_HIP(ctx, hipMalloc(&d_temp, temp_bytes ? temp_bytes : 1));
         AR_HIP(ctx, hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_code, d_code_sorted, d_order, ctx->d_perm, int(n_tris), 0, 30, ctx->stream));
-        k_tristream<<<blocks, 256, 0, ctx->stream>>>(ctx->d_vbo, ctx->d_idx, ctx->d_perm, n_verts, n_tris, ctx->tripos_stride, ctx->d_tripos,
+        k_tristream<true><<<blocks, 256, 0, ctx->stream>>>(ctx->d_vbo, ctx->d_idx, ctx->d_perm, n_verts, n_tris, ctx->tripos_stride, ctx->d_tripos,
                                                      ctx->d_triattr, ctx->d_tri, ctx->d_tri_t, ctx->d_box);
         AR_HIP(ctx, hipGetLastError());
         AR_HIP(ctx, hipStreamSynchronize(ctx->stream));

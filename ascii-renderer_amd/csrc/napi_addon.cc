@@ -770,6 +770,22 @@ napi_value js_set_id_output(napi_env env, napi_callback_info info) {
     return nullptr;
 }
 
+// updatePositions(handle, Float32Array data, floatsPerVertex (3 | 9), flags): ar_update_positions
+napi_value js_update_positions(napi_env env, napi_callback_info info) {
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    void *data;
+    size_t n;
+    if (!get_typed(env, argv[1], napi_float32_array, &data, &n, false)) return nullptr;
+    const int fpv = get_i32(env, argv[2]);
+    if ((fpv != 3 && fpv != 9) || n % size_t(fpv)) { napi_throw_range_error(env, nullptr, "updatePositions: 3 or 9 floats per vertex"); return nullptr; }
+    if (ar_update_positions(ctx, static_cast<const float *>(data), uint32_t(n / size_t(fpv)), fpv, get_i32(env, argv[3])))
+        return throw_ar(env, ctx, "ar_update_positions");
+    return nullptr;
+}
+
 napi_value init(napi_env env, napi_value exports) {
     const napi_property_descriptor props[] = {
         {"create", nullptr, js_create, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
@@ -794,6 +810,7 @@ napi_value init(napi_env env, napi_value exports) {
         {"allocHost", nullptr, js_alloc_host, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"quantizeColors", nullptr, js_quantize_colors, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"present", nullptr, js_present, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"updatePositions", nullptr, js_update_positions, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"renderAsync", nullptr, js_render_async, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readAsync", nullptr, js_read_async, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"wait", nullptr, js_wait, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

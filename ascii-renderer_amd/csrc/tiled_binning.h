@@ -226,6 +226,9 @@ __global__ __launch_bounds__(256) void k_morton(const float *__restrict__ vbo, c
 // nz, r, g, b, 0, 0), so a vertex is one 16-byte plus one 8-byte load.  box[6 * (s / 256) ..] = bounding box
 // (min xyz, max xyz) of the positions of each block of 256 slots (NaN coordinates left out).
 // A triangle that names a vertex outside the buffer gets NaN positions, which every later stage rejects.
+// ATTR = false (an update of positions alone, ar_update_positions): only what depends on the positions is rewritten -
+// the planes, the nine position floats of both records, the boxes; normals, colours and flags stay as they are.
+template <bool ATTR>
 __global__ __launch_bounds__(256) void k_tristream(const float *__restrict__ vbo, const uint32_t *__restrict__ idx,
                                                    const uint32_t *__restrict__ perm, uint32_t n_verts, uint32_t n_tris,
                                                    size_t stride, float *__restrict__ pos, float *__restrict__ attr,
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(256) void k_tristream(const float *__restrict__ vbo
             all_ok = all_ok && ok;
             const float *p = vbo + size_t(ok ? vi : 0u) * 9;
 #pragma unroll
-            for (int q = 0; q < 9; q++) a[v][q] = ok ? p[q] : 0.0f;
+            for (int q = 0; q < (ATTR ? 9 : 3); q++) a[v][q] = ok ? p[q] : 0.0f;
 #pragma unroll
             for (int ax = 0; ax < 3; ax++) {
                 const float x = ok ? p[ax] : __builtin_nanf("");
@@ -254,6 +257,16 @@ __global__ __launch_bounds__(256) void k_tristream(const float *__restrict__ vbo
                 lo[ax] = fminf(lo[ax], x); hi[ax] = fmaxf(hi[ax], x);  // (fminf / fmaxf drop a NaN operand)
             }
         }
+        if (!ATTR) {
+#pragma unroll
+            for (int v = 0; v < 3; v++)
+#pragma unroll
+                for (int ax = 0; ax < 3; ax++) {
+                    const float x = okv[v] ? a[v][ax] : __builtin_nanf("");
+                    tri_s[s].p[3 * v + ax] = x;
+                    tri_t[t].p[3 * v + ax] = x;
+                }
+        } else {
         float4 *row = reinterpret_cast<float4 *>(attr) + size_t(t) * 6;
         bool is_flat = all_ok;
 #pragma unroll
@@ -273,6 +286,7 @@ __global__ __launch_bounds__(256) void k_tristream(const float *__restrict__ vbo
         r.flags = (is_flat ? kFlagFlat : 0u) | (t << kFlagBits);
         tri_s[s] = r;
         tri_t[t] = r;
+        }
     }
 #pragma unroll
     for (int ax = 0; ax < 3; ax++)
@@ -324,6 +338,41 @@ __global__ __launch_bounds__(256) void k_build_vbo(const float *__restrict__ pos
         o[3] = float(nx); o[4] = float(ny); o[5] = float(nz);
         o[6] = r; o[7] = g; o[8] = b;
         idx[3 * size_t(t) + k] = 3u * t + uint32_t(k);
+    }
+}
+
+// In-place vertex updates (ar_update_positions).  k_put_positions: new positions (three floats per vertex) into the
+// position slots of the nine-float vertices.  k_flat_normals: every triangle's three vertices get the face normal exactly
+// as k_build_vbo computes it (meant for meshes whose triangles do not share vertices).
+__global__ __launch_bounds__(256) void k_put_positions(const float *__restrict__ positions, uint32_t n_verts, float *__restrict__ vbo) {
+    const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+    if (v >= n_verts) return;
+    float *o = vbo + size_t(v) * 9;
+    o[0] = positions[3 * size_t(v)]; o[1] = positions[3 * size_t(v) + 1]; o[2] = positions[3 * size_t(v) + 2];
+}
+
+__global__ __launch_bounds__(256) void k_flat_normals(float *__restrict__ vbo, const uint32_t *__restrict__ idx, uint32_t n_verts,
+                                                      uint32_t n_tris) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_tris) return;
+    uint32_t vi[3];
+    float p[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        vi[k] = idx[3 * size_t(t) + k];
+        if (vi[k] >= n_verts) return;  // (such a triangle is invisible anyway)
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++) p[k][ax] = vbo[size_t(vi[k]) * 9 + ax];
+    }
+    const double ux = double(p[1][0]) - double(p[0][0]), uy = double(p[1][1]) - double(p[0][1]), uz = double(p[1][2]) - double(p[0][2]);
+    const double vx = double(p[2][0]) - double(p[0][0]), vy = double(p[2][1]) - double(p[0][1]), vz = double(p[2][2]) - double(p[0][2]);
+    double nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+    const double L = sqrt((nx * nx + ny * ny) + nz * nz);
+    if (L > 1e-8) { nx /= L; ny /= L; nz /= L; } else { nx = 0.0; ny = 1.0; nz = 0.0; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float *o = vbo + size_t(vi[k]) * 9;
+        o[3] = float(nx); o[4] = float(ny); o[5] = float(nz);
     }
 }
 

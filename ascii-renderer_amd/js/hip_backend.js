@@ -401,6 +401,18 @@ export class HipRasterBackend {
     }
   }
 
+  // New vertex data for the mesh uploaded by the last setScene, in place (ar_update_positions): a Float32Array of 9 floats
+  // per vertex (position, normal, colour - the layout buildGeometry / meshToVbo produce) or 3 (positions only).  For a
+  // typed-array scene the vertices are the unshared ones meshToVbo lays out, three per triangle in index order;
+  // opts.flatNormals recomputes their face normals on the GPU, opts.resort picks a new spatial order.  A deforming mesh
+  // without another setScene - the reference would rebuild and upload everything (raster.js:130-133).
+  updatePositions(data, opts) {
+    this._ensure();
+    if (!(data instanceof Float32Array)) throw new TypeError('updatePositions: Float32Array expected');
+    const perVertex = opts && opts.floatsPerVertex ? opts.floatsPerVertex | 0 : (opts && opts.positionsOnly === false ? 9 : 3);
+    native().updatePositions(this._h, data, perVertex, ((opts && opts.flatNormals) ? 1 : 0) | ((opts && opts.resort) ? 2 : 0));
+  }
+
   // A model matrix for the mesh (column-major, 16 numbers; null removes it), applied on the GPU from the next frame
   // on: rigid motion of the scene without another setScene.  The reference's rasterizer has none
   // (raster_shader.js:12-13); see ar_set_model.

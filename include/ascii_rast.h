@@ -55,6 +55,24 @@ int ar_set_mesh(ar_ctx *ctx, const float *vbo9, uint32_t n_verts, const uint32_t
 int ar_set_mesh_indexed(ar_ctx *ctx, const float *positions, uint32_t n_verts, const uint32_t *indices, uint32_t n_tris,
                         const float *tri_colors);
 
+/* New vertex data for the current mesh, in place: data holds n_verts (the mesh's count) rows of floats_per_vertex
+ * floats - 9: whole vertices (pos3, nrm3, col3) as ar_set_mesh takes them; 3: positions only, normals and colours
+ * stay.  Topology, triangle indices (and with them winner ids and the tie rule) and the spatial order chosen at the
+ * last upload are kept; only the streams derived from the vertices are rewritten, on the GPU, ordered after the frames
+ * in flight and before the frames that follow without the host waiting for either (the copy from `data` is complete
+ * when the call returns).  The reference can only move a mesh by rebuilding and uploading it whole
+ * (RasterBackend.setScene -> _rebuildGeometry, raster.js:130-133,148-257); this is that per-frame rebuild for a
+ * deforming mesh at a fraction of ar_set_mesh's cost: no allocation (after the first call for a mesh of this size),
+ * no sort, and the host waits for nothing but its own copy.  flags:
+ *   AR_UPDATE_FLAT_NORMALS  every triangle's three vertices get normalize(cross(b-a, c-a)) of the new positions,
+ *                           computed as ar_set_mesh_indexed / pushTri do (raster.js:159-169) - for meshes whose
+ *                           triangles do not share vertices;
+ *   AR_UPDATE_RESORT        also choose a new spatial order, as an upload does (allocates and waits for the GPU):
+ *                           worth it once the mesh has moved far from the shape it was uploaded in. */
+#define AR_UPDATE_FLAT_NORMALS 1
+#define AR_UPDATE_RESORT 2
+int ar_update_positions(ar_ctx *ctx, const float *data, uint32_t n_verts, int floats_per_vertex, int flags);
+
 /* Copies the current mesh back in ar_set_mesh's layout (each pointer may be NULL); n_verts / n_tris receive
  * its size.  Counterpart of reading back the buffers given to gl.bufferData (raster.js:238-251); lets a
  * caller check or keep what ar_set_mesh_indexed built. */

@@ -406,6 +406,77 @@ def test_indexed_mesh_is_built_on_the_gpu_byte_for_byte(pkg, oracle, R):
     assert R.read_mesh()[1].size == 0
 
 
+def test_vertices_updated_in_place_between_frames_in_flight(pkg, oracle):
+    """ar_update_positions: a deforming mesh without another upload.  Frames are enqueued, the vertices replaced (whole
+    vertices; positions only; positions with the face normals recomputed on the GPU; with a new spatial order), more frames
+    enqueued - no waiting in between - and every frame read back must be the oracle's for the vertices it was enqueued
+    under.  Winner ids keep their meaning (the triangle's index)."""
+    r = pkg.Renderer(0)
+    try:
+        cols, rows = 320, 180
+        rng = np.random.default_rng(5)
+        P, I, C = pkg.geometry.random_mesh(0xBEEF, 40_000, cols, rows, 1.0)
+        vbo0, idx = pkg.host.mesh_to_vbo(P, I, C)
+        sc = pkg.scenes.random_scene(10, cols, rows, mesh_grid=(cols, rows))    # camera, lights, grid of the workload
+        r.set_mesh(vbo0, idx)
+        r.set_camera(sc["proj"], sc["view"]); r.set_lights(sc["lights"]); r.set_ascii()
+        r.set_id_output(True)
+        with pytest.raises(pkg.AsciiRastError):
+            r.update_positions(np.zeros((5, 3), np.float32))                    # wrong vertex count
+
+        def expect(vbo):
+            rgba, depth, ids = oracle.render(vbo, idx, sc["proj"], sc["view"], sc["lights"], cols, rows)
+            return rgba, depth, ids, oracle.quantize(rgba, cols, rows, pkg.scenes.DEFAULT_RAMP, 1, 2, 12)
+
+        def frames_then_read(vbo, label):
+            bufs = (r.host_array((rows, cols, 4), np.uint8), r.host_array((rows, cols), np.float32),
+                    r.host_array((rows, cols), np.uint8), r.host_array((rows, cols), np.uint32))
+            for _ in range(4):
+                r.render_async(cols, rows)
+            ticket = r.read_async(*bufs)
+            return bufs, ticket, expect(vbo), label
+
+        pending = [frames_then_read(vbo0, "as uploaded")]
+        # (1) whole vertices: positions jittered, colours changed
+        vbo1 = vbo0.copy()
+        vbo1[:, 0:3] += rng.normal(0, 0.02, size=(vbo1.shape[0], 3)).astype(np.float32)
+        vbo1[:, 6:9] = np.repeat(rng.uniform(0.2, 1.0, size=(vbo1.shape[0] // 3, 3)).astype(np.float32), 3, axis=0)  # one colour per triangle
+        r.update_positions(vbo1)
+        pending.append(frames_then_read(vbo1, "whole vertices"))
+        # (2) positions only: normals and colours stay
+        P2 = (vbo1[:, 0:3] * np.float32(1.01)).astype(np.float32)
+        vbo2 = vbo1.copy(); vbo2[:, 0:3] = P2
+        r.update_positions(P2)
+        pending.append(frames_then_read(vbo2, "positions only"))
+        # (3) positions with face normals recomputed: the vertex buffer mesh_to_vbo builds from the new positions
+        P3 = (P2 + rng.normal(0, 0.05, size=P2.shape)).astype(np.float32)
+        tri_col = vbo2[0::3, 6:9].copy()
+        vbo3, idx3 = pkg.host.mesh_to_vbo(P3, np.arange(P3.shape[0], dtype=np.uint32), tri_col)
+        assert np.array_equal(idx3, idx)
+        r.update_positions(P3, flat_normals=True)
+        pending.append(frames_then_read(vbo3, "flat normals"))
+        for bufs, ticket, (rgba, depth, ids, asc), label in pending:
+            r.wait(ticket)
+            assert np.array_equal(bufs[3], ids), label
+            assert np.array_equal(bufs[1].view(np.uint32), depth.view(np.uint32)), label
+            assert np.array_equal(bufs[0], rgba), label
+            assert np.array_equal(bufs[2], asc), label
+        got_vbo, got_idx = r.read_mesh()
+        assert np.array_equal(got_vbo.view(np.uint32), vbo3.view(np.uint32)) and np.array_equal(got_idx, idx)
+        # (4) a new spatial order on request; and the direct path sees the same vertices
+        P4 = (P3[::-1] * np.float32(0.5) + np.float32(0.5) * P3).astype(np.float32)
+        vbo4 = vbo3.copy(); vbo4[:, 0:3] = P4
+        r.update_positions(P4, resort=True)
+        rgba, depth, ids, asc = expect(vbo4)
+        for path in (0, 1):
+            r.set_option("path", path)
+            out = r.render(cols, rows, want_ids=True)
+            assert np.array_equal(out["ids"], ids) and np.array_equal(out["rgba"], rgba) and np.array_equal(out["ascii"], asc), path
+            assert np.array_equal(out["depth"].view(np.uint32), depth.view(np.uint32)), path
+    finally:
+        r.close()
+
+
 def test_pool_overflow_falls_back_and_stays_exact(pkg, oracle):
     """A record pool far too small for the frame: some binning workgroups must resolve through the
     global key buffer, and the merged result is still bit-exact - also on the following frames."""
