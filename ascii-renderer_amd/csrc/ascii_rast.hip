@@ -50,7 +50,7 @@
 // waits for its stream, so it is not itself capturable).  Every GPU the library runs on holds its own copy of the array until the process
 // ends; all calls on a GPU share it, so calls that overlap on one GPU race, and it keeps the last call's contents
 // (nothing in it has to start at zero: a call overwrites every byte it later reads).
-static __device__ __align__(256) unsigned char scratch[size_t(AR_STATIC_MAX_CELLS) * 5];  // RGBA staging, then the ASCII plane
+static __device__ __align__(256) unsigned char scratch[size_t(AR_STATIC_MAX_CELLS) * 6];  // RGBA staging, the ASCII plane, the ramp-index plane
 
 namespace {
 
@@ -135,7 +135,7 @@ void ar_destroy(ar_ctx *ctx) {
     free_targets(ctx);
     (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx);
     (void)hipFree(ctx->d_medium); (void)hipFree(ctx->d_large); (void)hipFree(ctx->d_counters);
-    (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii); (void)hipFree(ctx->d_q_colors);
+    (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii); (void)hipFree(ctx->d_q_plane); (void)hipFree(ctx->d_q_colors);
     (void)hipFree(ctx->d_p_atlas); (void)hipFree(ctx->d_p_cov); (void)hipFree(ctx->d_p_image);
     (void)hipFree(ctx->d_state); (void)hipFree(ctx->d_tripos); (void)hipFree(ctx->d_triattr); (void)hipFree(ctx->d_tri);
     (void)hipFree(ctx->d_triuv); (void)hipFree(ctx->d_atlas); (void)hipFree(ctx->d_rt);
@@ -569,10 +569,11 @@ int quantize_to_device(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows) {
     const size_t n = size_t(cols) * rows;
     if (n > ctx->q_cells) {
         AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii);
-        ctx->d_q_rgba = nullptr; ctx->d_q_ascii = nullptr; ctx->q_cells = 0;
+        (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii); (void)hipFree(ctx->d_q_plane);
+        ctx->d_q_rgba = nullptr; ctx->d_q_ascii = nullptr; ctx->d_q_plane = nullptr; ctx->q_cells = 0;
         AR_HIP(ctx, hipMalloc(&ctx->d_q_rgba, n * 4));
         AR_HIP(ctx, hipMalloc(&ctx->d_q_ascii, n));
+        AR_HIP(ctx, hipMalloc(&ctx->d_q_plane, n));
         ctx->q_cells = n;
     }
     FrameParams fp = ctx->fp;
@@ -580,7 +581,7 @@ int quantize_to_device(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows) {
     AR_HIP(ctx, hipMemcpyAsync(ctx->d_q_rgba, rgba, n * 4, hipMemcpyHostToDevice, ctx->stream));
     {
         Stamper s(ctx, K_ASCII);
-        if (fp.mode_on == 1) launch_ascii<true>(fp, ctx->d_q_rgba, ctx->d_q_ascii, ctx->stream);
+        if (fp.mode_on == 1) launch_ascii_rgba(fp, reinterpret_cast<const uint32_t *>(ctx->d_q_rgba), ctx->d_q_plane, false, ctx->d_q_ascii, ctx->stream);
         else k_quantize_plain<<<unsigned((n + 255) / 256), 256, 0, ctx->stream>>>(fp, reinterpret_cast<const uint32_t *>(ctx->d_q_rgba), ctx->d_q_ascii, n);
     }
     AR_HIP(ctx, hipGetLastError());
@@ -612,11 +613,11 @@ int ar_quantize_static(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uin
     unsigned char *base = nullptr;
     int rc = static_scratch(ctx, &base);  // (normally found at ar_create; looked up again here if that failed, and reported here)
     if (rc) return rc;
-    uint8_t *d_rgba = base, *d_ascii = base + size_t(AR_STATIC_MAX_CELLS) * 4;
+    uint8_t *d_rgba = base, *d_ascii = base + size_t(AR_STATIC_MAX_CELLS) * 4, *d_plane = base + size_t(AR_STATIC_MAX_CELLS) * 5;
     FrameParams fp = ctx->fp;
     fp.cols = cols; fp.rows = rows; fp.row0 = 0; fp.row1 = rows; fp.ya = 0; fp.yb = rows;
     AR_HIP(ctx, hipMemcpyAsync(d_rgba, rgba, n * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (fp.mode_on == 1) launch_ascii<true>(fp, d_rgba, d_ascii, ctx->stream);
+    if (fp.mode_on == 1) launch_ascii_rgba(fp, reinterpret_cast<const uint32_t *>(d_rgba), d_plane, false, d_ascii, ctx->stream);
     else k_quantize_plain<<<unsigned((n + 255) / 256), 256, 0, ctx->stream>>>(fp, reinterpret_cast<const uint32_t *>(d_rgba), d_ascii, n);
     hipError_t launched = hipGetLastError();
     if (launched == hipSuccess) launched = hipMemcpyAsync(ascii, d_ascii, n, hipMemcpyDeviceToHost, ctx->stream);
@@ -730,7 +731,7 @@ int ar_rt_render_async(ar_ctx *ctx, int cols, int rows, const float cam_pos[3], 
     {
         Stamper s(ctx, K_ASCII);
         if (fp.mode_on == 1) {
-            launch_ascii<true>(fp, ctx->d_rgba[0], ascii_out, ctx->stream);
+            launch_ascii_rgba(fp, reinterpret_cast<const uint32_t *>(ctx->d_rgba[0]), ctx->d_ridx[0], false, ascii_out, ctx->stream);
         } else {
             const size_t first = size_t(row0) * cols, n = size_t(row1 - row0) * cols;
             k_quantize_plain<<<unsigned((n + 255) / 256), 256, 0, ctx->stream>>>(
@@ -856,10 +857,11 @@ int ar_quantize_colors(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, int
     if (grayscale) return colors_from_device(ctx, nullptr, n, steps, grayscale, colors);
     if (n > ctx->q_cells) {
         AR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii);
-        ctx->d_q_rgba = nullptr; ctx->d_q_ascii = nullptr; ctx->q_cells = 0;
+        (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii); (void)hipFree(ctx->d_q_plane);
+        ctx->d_q_rgba = nullptr; ctx->d_q_ascii = nullptr; ctx->d_q_plane = nullptr; ctx->q_cells = 0;
         AR_HIP(ctx, hipMalloc(&ctx->d_q_rgba, n * 4));
         AR_HIP(ctx, hipMalloc(&ctx->d_q_ascii, n));
+        AR_HIP(ctx, hipMalloc(&ctx->d_q_plane, n));
         ctx->q_cells = n;
     }
     AR_HIP(ctx, hipMemcpyAsync(ctx->d_q_rgba, rgba, n * 4, hipMemcpyHostToDevice, ctx->stream));

@@ -249,8 +249,15 @@ __global__ __launch_bounds__(256) void k_ascii_plane(FrameParams fp, const uint8
 //                                                           cells are queued and a second step runs the shader's two
 //                                                           passes on them as written, from the staged tile.
 // The codes go through LDS so that the queued cells' bytes are in place before a lane stores its four.
-template <int R>
-__global__ __launch_bounds__(256) void k_ascii_counts(FrameParams fp, const uint8_t *__restrict__ src, uint8_t *__restrict__ ascii) {
+// OV: the plane may hold kPlaneOverride (255) for cells whose alpha byte is a literal code (2..254: UI cells, atlas
+// glyphs).  Such a cell is not smoothed - its code is the alpha byte of rgba - and does not vote: it adds nothing to
+// the count words, and a sticky bit above the ten fields (set per column when any of its cells is one) sends every
+// cell with one in its window to the second step, which runs the shader's passes with the cell skipped, as the shader
+// does (ascii_pass_shader.js:98,125).  Overrides are sparse (a border, a line of text), so few cells take that road.
+constexpr int kPlaneOverride = 255;
+template <int R, bool OV>
+__global__ __launch_bounds__(256) void k_ascii_counts(FrameParams fp, const uint8_t *__restrict__ src, const uint32_t *__restrict__ rgba,
+                                                      uint8_t *__restrict__ ascii) {
     constexpr int TWD = 34, TH = 8 + 2 * R;  // as k_ascii_plane: dwords per tile row (4 bytes of halo either side), tile rows
     constexpr int N = (2 * R + 1) * (2 * R + 1) - 1, NC = 4 + 2 * R;
     constexpr unsigned long long kOnes = 0x0041041041041041ull;  // bit 0 of each of the ten 6-bit fields
@@ -299,15 +306,25 @@ __global__ __launch_bounds__(256) void k_ascii_counts(FrameParams fp, const uint
         for (int item = int(threadIdx.x); item < 2 * NCOL; item += 256) {
             const int half = item >= NCOL ? 1 : 0, cb = item - half * NCOL;
             const uint8_t *column = cells + (4 * half) * (TWD * 4) + (4 - R) + cb;  // tile row 4 half: the first window row of output row 4 half
+            // (a plane without override cells holds only ramp indices below ten: it is written by kernels of the same
+            // frame under the same ramp - k_tile, k_shade, k_plane_from_rgba - and only rows written this frame are read)
+            auto one = [](int v) { return OV ? (v < 10 ? 1ull << (6 * v) : 0ull) : 1ull << (6 * v); };
             unsigned long long acc = 0ull;
+            int ovc = 0;  // override cells among the column's 2R + 1 (OV only)
 #pragma unroll
-            for (int t = 0; t <= 2 * R; t++) acc += 1ull << (6 * int(column[t * (TWD * 4)]));
-            colsum[(4 * half) * NCOL + cb] = acc;
+            for (int t = 0; t <= 2 * R; t++) {
+                const int v = int(column[t * (TWD * 4)]);
+                acc += one(v);
+                if (OV) ovc += v == kPlaneOverride ? 1 : 0;
+            }
+            colsum[(4 * half) * NCOL + cb] = acc | (OV && ovc ? 1ull << 60 : 0ull);
 #pragma unroll
             for (int ro = 1; ro < 4; ro++) {
-                acc += 1ull << (6 * int(column[(ro + 2 * R) * (TWD * 4)]));
-                acc -= 1ull << (6 * int(column[(ro - 1) * (TWD * 4)]));
-                colsum[(4 * half + ro) * NCOL + cb] = acc;
+                const int vin = int(column[(ro + 2 * R) * (TWD * 4)]), vout = int(column[(ro - 1) * (TWD * 4)]);
+                acc += one(vin);
+                acc -= one(vout);
+                if (OV) ovc += (vin == kPlaneOverride ? 1 : 0) - (vout == kPlaneOverride ? 1 : 0);
+                colsum[(4 * half + ro) * NCOL + cb] = acc | (OV && ovc ? 1ull << 60 : 0ull);
             }
         }
     }
@@ -324,8 +341,17 @@ __global__ __launch_bounds__(256) void k_ascii_counts(FrameParams fp, const uint
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int base = int((centre >> (8 * j)) & 255u);
-            const unsigned long long cnt = win - (1ull << (6 * base));  // the neighbours: the window without the cell itself
+            const unsigned long long here = win;
             if (j < 3) win += col[j + 2 * R + 1] - col[j];
+            if (OV && base == kPlaneOverride) {  // a literal code: the alpha byte, never smoothed
+                out |= (x + j < fp.cols ? rgba[size_t(y) * fp.cols + x + j] >> 24 : 0u) << (8 * j);
+                continue;
+            }
+            if (OV && (here >> 60) != 0ull) {    // an override cell in the window: the shader's passes decide, without it
+                queue[atomicAdd(&n_queue, 1u)] = uint16_t(ly * 128 + 4 * lx + j);
+                continue;                        // (the second step writes this byte of the word in LDS)
+            }
+            const unsigned long long cnt = here - (1ull << (6 * base));  // the neighbours: the window without the cell itself
             int fin = base;
             const unsigned long long reach = (cnt + k_thresh) & kTop;
             if (reach != 0ull) {
@@ -360,13 +386,14 @@ __global__ __launch_bounds__(256) void k_ascii_counts(FrameParams fp, const uint
         int cand = -1, count = 0, votes = 0;
 #pragma unroll
         for (int q = 0; q < N; q++) {
+            if (OV && nb[q] == kPlaneOverride) continue;  // override cells do not vote
             if (count == 0) { cand = nb[q]; count = 1; }
             else if (nb[q] == cand) count += 1;
             else count -= 1;
         }
 #pragma unroll
         for (int q = 0; q < N; q++) votes += nb[q] == cand ? 1 : 0;
-        const int fin = (votes >= thresh && cand != base) ? cand : base;
+        const int fin = (cand >= 0 && votes >= thresh && cand != base) ? cand : base;
         reinterpret_cast<uint8_t *>(codes)[cell] = (fin >= 0 && fin < fp.ramp_len) ? ramp[fin] : uint8_t(32);
     }
     __syncthreads();
@@ -382,15 +409,38 @@ __global__ __launch_bounds__(256) void k_ascii_counts(FrameParams fp, const uint
     }
 }
 
+// RGBA8 grid -> plane of ramp indices over rows [ya, yb), kPlaneOverride where the alpha byte is a literal code: the input
+// of the counting kernel for grids that do not come with a plane (AsciiPass.drawFromBuffer's input, ray frames).
+__global__ __launch_bounds__(256) void k_plane_from_rgba(FrameParams fp, const uint32_t *__restrict__ px, uint8_t *__restrict__ plane) {
+    const size_t first = size_t(fp.ya) * fp.cols, n = size_t(fp.yb - fp.ya) * fp.cols;
+    const size_t p = size_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t me = px[first + p];
+    const int a = int(me >> 24);
+    plane[first + p] = (a >= 2 && a <= 254) ? uint8_t(kPlaneOverride)
+                                            : uint8_t(ramp_index(int(me & 255u), int((me >> 8) & 255u), int((me >> 16) & 255u), fp.ramp_len));
+}
+
+// The counting kernel's domain: ramps of at most ten glyphs, radius 1 or 2, thresholds that fit a field.
+inline bool ascii_counts_domain(const FrameParams &fp) {
+    const int radius = fp.mode_radius < 1 ? 1 : (fp.mode_radius > 3 ? 3 : fp.mode_radius);
+    return fp.ramp_len <= 10 && radius <= 2 && fp.mode_thresh >= 1 && fp.mode_thresh <= 32;
+}
+
+// Smoothing of an RGBA8 grid that may carry literal codes in its alpha bytes: through a plane of ramp indices with the
+// override cells marked (plane: scratch of cols * rows bytes; already filled when plane_ready - k_tile writes one for
+// textured frames) and the counting kernel when the parameters allow, else the generic kernel straight from the grid.
+inline void launch_ascii_rgba(const FrameParams &fp, const uint32_t *rgba, uint8_t *plane, bool plane_ready, uint8_t *ascii, hipStream_t stream);
+
 template <bool FROM_RGBA>
 void launch_ascii(const FrameParams &fp, const void *src, uint8_t *ascii, hipStream_t stream) {
     const int radius = fp.mode_radius < 1 ? 1 : (fp.mode_radius > 3 ? 3 : fp.mode_radius);  // shader clamps to 1..3
     if constexpr (!FROM_RGBA) {
         const dim3 grid((fp.cols + 127) / 128, (fp.row1 - fp.row0 + 7) / 8);
         const uint8_t *plane = static_cast<const uint8_t *>(src);
-        if (fp.ramp_len <= 10 && radius <= 2 && fp.mode_thresh >= 1 && fp.mode_thresh <= 32) {  // the counting kernel's domain
-            if (radius == 1) k_ascii_counts<1><<<grid, 256, 0, stream>>>(fp, plane, ascii);
-            else k_ascii_counts<2><<<grid, 256, 0, stream>>>(fp, plane, ascii);
+        if (ascii_counts_domain(fp)) {
+            if (radius == 1) k_ascii_counts<1, false><<<grid, 256, 0, stream>>>(fp, plane, nullptr, ascii);
+            else k_ascii_counts<2, false><<<grid, 256, 0, stream>>>(fp, plane, nullptr, ascii);
             return;
         }
         if (radius == 1) k_ascii_plane<1><<<grid, 256, 0, stream>>>(fp, plane, ascii);
@@ -402,6 +452,21 @@ void launch_ascii(const FrameParams &fp, const void *src, uint8_t *ascii, hipStr
         else if (radius == 2) k_ascii<2, FROM_RGBA><<<grid, 256, 0, stream>>>(fp, src, ascii);
         else k_ascii<3, FROM_RGBA><<<grid, 256, 0, stream>>>(fp, src, ascii);
     }
+}
+
+inline void launch_ascii_rgba(const FrameParams &fp, const uint32_t *rgba, uint8_t *plane, bool plane_ready, uint8_t *ascii, hipStream_t stream) {
+    if (!plane || !ascii_counts_domain(fp)) {
+        launch_ascii<true>(fp, rgba, ascii, stream);
+        return;
+    }
+    const int radius = fp.mode_radius < 1 ? 1 : (fp.mode_radius > 2 ? 2 : fp.mode_radius);
+    if (!plane_ready) {
+        const size_t n = size_t(fp.yb - fp.ya) * fp.cols;
+        k_plane_from_rgba<<<unsigned((n + 255) / 256), 256, 0, stream>>>(fp, rgba, plane);
+    }
+    const dim3 grid((fp.cols + 127) / 128, (fp.row1 - fp.row0 + 7) / 8);
+    if (radius == 1) k_ascii_counts<1, true><<<grid, 256, 0, stream>>>(fp, plane, rgba, ascii);
+    else k_ascii_counts<2, true><<<grid, 256, 0, stream>>>(fp, plane, rgba, ascii);
 }
 
 }  // namespace

@@ -87,7 +87,7 @@ struct ar_ctx {
     BinState *d_state = nullptr;     // kSets blocks
     uint32_t frame = 0;              // tiled frames enqueued so far
     bool last_tiled = false;
-    uint8_t *d_q_rgba = nullptr, *d_q_ascii = nullptr;
+    uint8_t *d_q_rgba = nullptr, *d_q_ascii = nullptr, *d_q_plane = nullptr;  // ar_quantize staging: grid, codes, ramp-index plane
     size_t q_cells = 0;
     uint32_t *d_q_colors = nullptr;
     size_t qc_cells = 0;
@@ -460,7 +460,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
     if (fp.mode_on == 1) {
         Stamper s(ctx, K_ASCII, fs);
         // a textured frame can hold ASCII overrides in its alpha bytes, which the plane of ramp indices cannot express
-        if (textured) launch_ascii<true>(fp, ctx->d_rgba[oset], ascii_out, fs);
+        if (textured) launch_ascii_rgba(fp, reinterpret_cast<const uint32_t *>(ctx->d_rgba[oset]), ctx->d_ridx[tiled ? set : 0], false, ascii_out, fs);
         else launch_ascii<false>(fp, ctx->d_ridx[tiled ? set : 0], ascii_out, fs);
     }
     AR_HIP(ctx, hipGetLastError());

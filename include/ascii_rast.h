@@ -212,7 +212,7 @@ int ar_frame_wait_stream(ar_ctx *ctx, void *hip_stream);
 int ar_quantize(ar_ctx *ctx, const uint8_t *rgba, int cols, int rows, uint8_t *ascii);
 
 /* ar_quantize for callers that cannot allocate: same arguments, same result, but the grid and the ASCII plane are
- * staged in a fixed device array that is part of the library's code object (AR_STATIC_MAX_CELLS x 5 bytes on every
+ * staged in a fixed device array that is part of the library's code object (AR_STATIC_MAX_CELLS x 6 bytes on every
  * GPU the library runs on, held until the process ends), so the call makes no hipMalloc / hipFree.  It has NO
  * counterpart in the reference; it exists for callers that cannot allocate: tight serving loops, harnesses that
  * forbid allocation, threads that run while another captures a HIP graph (the call itself waits for its stream and

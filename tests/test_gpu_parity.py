@@ -843,6 +843,28 @@ def test_quantize_modal_vs_oracle(pkg, oracle, R):
         got = R.quantize(rgba, cols, rows)
         want = oracle.quantize(rgba, cols, rows, "@%#*+=-:. ", 1, radius, thresh)
         assert np.array_equal(got, want), (cols, rows)
+    # override cells (alpha 2..254) as the non-voting class of the counting kernel: every density from none to all, a UI
+    # border and a line of text as the reference's caller writes them (js/main.js:342-361), thresholds on both sides
+    # of the majority, both radii the kernel takes, short and full ramps - and a ramp beyond its domain
+    for case, (cols, rows, radius, thresh, ramp, density) in enumerate([
+            (200, 60, 2, 12, "@%#*+=-:. ", 0.0), (200, 60, 2, 12, "@%#*+=-:. ", 0.05), (200, 60, 2, 12, "@%#*+=-:. ", 0.5),
+            (200, 60, 2, 12, "@%#*+=-:. ", 1.0), (131, 47, 2, 5, "@%#*+=-:. ", 0.1), (131, 47, 2, 13, "@#. ", 0.1),
+            (131, 47, 2, 24, "@ ", 0.02), (131, 47, 1, 4, "@%#*+=-:. ", 0.1), (131, 47, 1, 1, "@%#*+=-:. ", 0.2),
+            (131, 47, 2, 12, "@%#*+=-:. ab", 0.1), (640, 360, 2, 12, "@%#*+=-:. ", 0.0)]):
+        lv = rng.choice([0, 20, 60, 90, 140, 200, 250], size=(rows, cols), p=[0.4, 0.1, 0.1, 0.1, 0.1, 0.1, 0.1]).astype(np.uint8)
+        rgba = np.stack([lv, lv // 2 + 10, lv, np.full_like(lv, 255)], axis=2)
+        ov = rng.random((rows, cols)) < density
+        rgba[ov, 3] = rng.integers(2, 255, size=int(ov.sum()))
+        if case == 10:                                                     # the application's frame: border and text in alpha
+            for (y, x0, text) in [(0, 0, "3" * cols), (rows - 1, 0, "1" * cols), (5, 10, "41.59 fps")]:
+                for i, ch in enumerate(text):
+                    rgba[y, x0 + i] = (0, 0, 0, ord(ch))
+            rgba[:, 0] = (0, 0, 0, ord("4")); rgba[:, -1] = (0, 0, 0, ord("1"))
+        R.set_ascii(ramp, True, radius, thresh)
+        got = R.quantize(rgba, cols, rows)
+        want = oracle.quantize(rgba, cols, rows, ramp, 1, radius, thresh)
+        assert np.array_equal(got, want), (case, int(np.count_nonzero(got != want)))
+    R.set_ascii()
 
 
 def test_randomised_sweep_against_oracle():
