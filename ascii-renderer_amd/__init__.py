@@ -5,6 +5,6 @@ The product is the HIP library (csrc/, C ABI in include/ascii_rast.h) and its Ja
 pytest suite and bench.py use to drive the same C ABI.
 """
 from . import binding, geometry, host, scenes  # noqa: F401
-from .binding import AsciiRastError, Renderer, load_library  # noqa: F401
+from .binding import AsciiRastError, Group, Renderer, load_library, strip_rows  # noqa: F401
 
-__all__ = ["binding", "geometry", "host", "scenes", "Renderer", "AsciiRastError", "load_library"]
+__all__ = ["binding", "geometry", "host", "scenes", "Renderer", "Group", "AsciiRastError", "load_library", "strip_rows"]

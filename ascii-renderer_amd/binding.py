@@ -19,6 +19,8 @@ EXPORTS = [
     "ar_frame_counters", "ar_set_option", "ar_set_mesh_uv", "ar_set_texture", "ar_set_mesh_indexed", "ar_read_mesh",
     "ar_rt_set_scene", "ar_rt_render", "ar_rt_render_async", "ar_quantize_static", "ar_set_model",
     "ar_read_async", "ar_wait", "ar_poll", "ar_update_positions",
+    "ar_strip_rows", "ar_group_create", "ar_group_destroy", "ar_group_last_error", "ar_group_size", "ar_group_ctx",
+    "ar_group_render_async", "ar_group_sync", "ar_group_frames_gathered", "ar_group_read",
 ]
 _lib = None
 
@@ -94,6 +96,23 @@ def load_library():
     L.ar_poll.argtypes = [vp, ctypes.c_uint64]
     for name in ("ar_read_async", "ar_wait", "ar_poll"):
         getattr(L, name).restype = ctypes.c_int
+    _ip = ctypes.POINTER(ctypes.c_int)
+    L.ar_strip_rows.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip, _ip]
+    L.ar_group_create.argtypes = [ctypes.c_int, _ip, ctypes.c_int]
+    L.ar_group_create.restype = vp
+    L.ar_group_destroy.argtypes = [vp]
+    L.ar_group_destroy.restype = None
+    L.ar_group_last_error.argtypes = [vp]
+    L.ar_group_last_error.restype = ctypes.c_char_p
+    L.ar_group_size.argtypes = [vp]
+    L.ar_group_ctx.argtypes = [vp, ctypes.c_int]
+    L.ar_group_ctx.restype = vp
+    L.ar_group_render_async.argtypes = [vp, ctypes.c_int, ctypes.c_int, _fp, _fp]
+    L.ar_group_sync.argtypes = [vp]
+    L.ar_group_frames_gathered.argtypes = [vp]
+    L.ar_group_read.argtypes = [vp, ctypes.c_int, ctypes.c_int, _u8p]
+    for name in ("ar_strip_rows", "ar_group_size", "ar_group_render_async", "ar_group_sync", "ar_group_frames_gathered", "ar_group_read"):
+        getattr(L, name).restype = ctypes.c_int
     L.ar_device_buffer.argtypes = [vp, ctypes.c_int]
     L.ar_device_buffer.restype = vp
     L.ar_stream.argtypes = [vp]
@@ -131,12 +150,22 @@ def _f32(a):
     return a, a.ctypes.data_as(_fp)
 
 
+def strip_rows(rows, n_strips, strip):
+    """(row0, row1) of one strip when `rows` rows are cut into n_strips (ar_strip_rows: plain arithmetic, no GPU)."""
+    L = load_library()
+    a, b = ctypes.c_int(0), ctypes.c_int(0)
+    if L.ar_strip_rows(int(rows), int(n_strips), int(strip), ctypes.byref(a), ctypes.byref(b)):
+        raise ValueError("bad strip %d of %d over %d rows" % (strip, n_strips, rows))
+    return a.value, b.value
+
+
 class Renderer:
     """One GPU renderer context (ar_ctx).  Outputs are numpy arrays, row 0 = top of the image."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed=None):
         self._L = load_library()
-        self._h = self._L.ar_create(int(device))
+        self._owned = _borrowed is None
+        self._h = self._L.ar_create(int(device)) if self._owned else _borrowed
         if not self._h:
             raise AsciiRastError("ar_create failed: " + (self._L.ar_last_error(None) or b"").decode())
         self.cols = self.rows = 0
@@ -147,7 +176,8 @@ class Renderer:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.ar_destroy(self._h)
+            if self._owned:
+                self._L.ar_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -467,3 +497,54 @@ class Renderer:
 
     def set_option(self, name, value):
         self._check(self._L.ar_set_option(self._h, {"path": 1, "pool_records": 2, "overlap": 3, "tile_rows": 4, "work_classes": 5, "fold_scan": 6}[name], int(value)))
+
+
+class Group:
+    """Several GPUs in one process (ar_group): one frame cut into row strips, a context and a host thread per device,
+    the ASCII strips combined by RCCL all-gathers every `batch` frames."""
+
+    def __init__(self, device_ids, batch=16):
+        self._L = load_library()
+        ids = (ctypes.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        self._g = self._L.ar_group_create(len(device_ids), ids, int(batch))
+        if not self._g:
+            raise AsciiRastError("ar_group_create failed: " + (self._L.ar_group_last_error(None) or b"").decode())
+        self.n, self.batch = len(device_ids), int(batch)
+        self.members = [Renderer(_borrowed=self._L.ar_group_ctx(self._g, i)) for i in range(self.n)]
+        self.cols = self.rows = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise AsciiRastError((self._L.ar_group_last_error(self._g) or b"").decode() + " (code %d)" % rc)
+
+    def close(self):
+        if getattr(self, "_g", None):
+            for m in self.members:
+                m.close()
+            self._L.ar_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render_async(self, cols, rows, prepared_camera):
+        """One frame on every member; prepared_camera as Renderer.prepare_camera returns it."""
+        rc = self._L.ar_group_render_async(self._g, int(cols), int(rows), prepared_camera[0], prepared_camera[1])
+        if rc:
+            self._check(rc)
+        self.cols, self.rows = int(cols), int(rows)
+
+    def sync(self):
+        self._check(self._L.ar_group_sync(self._g))
+
+    def frames_gathered(self):
+        return self._L.ar_group_frames_gathered(self._g)
+
+    def read(self, frame=0, member=0):
+        """uint8 [rows, cols]: frame `frame` of the last gathered batch as member `member` holds it."""
+        out = np.zeros((self.rows, self.cols), dtype=np.uint8)
+        self._check(self._L.ar_group_read(self._g, int(member), int(frame), out.ctypes.data_as(_u8p)))
+        return out

@@ -969,3 +969,5 @@ int ar_set_option(ar_ctx *ctx, int option, long long value) {
 }
 
 }  // extern "C"
+
+#include "group.h"

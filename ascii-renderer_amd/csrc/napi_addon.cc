@@ -24,11 +24,22 @@ namespace {
 
 struct Handle {
     ar_ctx *ctx;
+    bool owned;  // false for a member of a group: the group destroys it
 };
 
 void finalize_handle(napi_env, void *data, void *) {
     Handle *h = static_cast<Handle *>(data);
-    if (h->ctx) ar_destroy(h->ctx);
+    if (h->ctx && h->owned) ar_destroy(h->ctx);
+    delete h;
+}
+
+struct GroupHandle {
+    ar_group *group;
+};
+
+void finalize_group(napi_env, void *data, void *) {
+    GroupHandle *h = static_cast<GroupHandle *>(data);
+    if (h->group) ar_group_destroy(h->group);
     delete h;
 }
 
@@ -90,7 +101,7 @@ napi_value js_create(napi_env env, napi_callback_info info) {
     if (!get_args(env, info, 1, argv)) return nullptr;
     ar_ctx *ctx = ar_create(get_i32(env, argv[0]));
     if (!ctx) return throw_ar(env, nullptr, "ar_create");
-    Handle *h = new Handle{ctx};
+    Handle *h = new Handle{ctx, true};
     napi_value ext;
     NAPI_OK(env, napi_create_external(env, h, finalize_handle, nullptr, &ext));
     return ext;
@@ -102,7 +113,7 @@ napi_value js_destroy(napi_env env, napi_callback_info info) {
     void *p = nullptr;
     if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
         Handle *h = static_cast<Handle *>(p);
-        if (h->ctx) { ar_destroy(h->ctx); h->ctx = nullptr; }  // idempotent, like RasterBackend.dispose
+        if (h->ctx) { if (h->owned) ar_destroy(h->ctx); h->ctx = nullptr; }  // idempotent, like RasterBackend.dispose
     }
     return nullptr;
 }
@@ -786,6 +797,127 @@ napi_value js_update_positions(napi_env env, napi_callback_info info) {
     return nullptr;
 }
 
+ar_group *get_group(napi_env env, napi_value v) {
+    void *p = nullptr;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !static_cast<GroupHandle *>(p)->group) {
+        napi_throw_type_error(env, nullptr, "ascii_rast addon: invalid or destroyed group handle");
+        return nullptr;
+    }
+    return static_cast<GroupHandle *>(p)->group;
+}
+
+napi_value throw_group(napi_env env, ar_group *g, const char *what) {
+    char msg[384];
+    snprintf(msg, sizeof msg, "%s: %s", what, ar_group_last_error(g));
+    napi_throw_error(env, nullptr, msg);
+    return nullptr;
+}
+
+// stripRows(rows, nStrips, strip) -> [row0, row1]: ar_strip_rows
+napi_value js_strip_rows(napi_env env, napi_callback_info info) {
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return nullptr;
+    int row0 = 0, row1 = 0;
+    if (ar_strip_rows(get_i32(env, argv[0]), get_i32(env, argv[1]), get_i32(env, argv[2]), &row0, &row1)) {
+        napi_throw_range_error(env, nullptr, "stripRows: bad arguments");
+        return nullptr;
+    }
+    napi_value arr, a, b;
+    NAPI_OK(env, napi_create_array_with_length(env, 2, &arr));
+    napi_create_int32(env, row0, &a);
+    napi_create_int32(env, row1, &b);
+    napi_set_element(env, arr, 0, a);
+    napi_set_element(env, arr, 1, b);
+    return arr;
+}
+
+// groupCreate(Int32Array deviceIds, batch) -> group handle: ar_group_create
+napi_value js_group_create(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    void *ids;
+    size_t n;
+    if (!get_typed(env, argv[0], napi_int32_array, &ids, &n, false)) return nullptr;
+    ar_group *g = ar_group_create(int(n), static_cast<const int *>(ids), get_i32(env, argv[1]));
+    if (!g) return throw_group(env, nullptr, "ar_group_create");
+    GroupHandle *h = new GroupHandle{g};
+    napi_value ext;
+    NAPI_OK(env, napi_create_external(env, h, finalize_group, nullptr, &ext));
+    return ext;
+}
+
+napi_value js_group_destroy(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    void *p = nullptr;
+    if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
+        GroupHandle *h = static_cast<GroupHandle *>(p);
+        if (h->group) { ar_group_destroy(h->group); h->group = nullptr; }
+    }
+    return nullptr;
+}
+
+// groupCtx(group, member) -> renderer handle of that member (owned by the group; valid until groupDestroy): ar_group_ctx
+napi_value js_group_ctx(napi_env env, napi_callback_info info) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return nullptr;
+    ar_group *g = get_group(env, argv[0]);
+    if (!g) return nullptr;
+    ar_ctx *ctx = ar_group_ctx(g, get_i32(env, argv[1]));
+    if (!ctx) { napi_throw_range_error(env, nullptr, "groupCtx: no such member"); return nullptr; }
+    Handle *h = new Handle{ctx, false};
+    napi_value ext;
+    NAPI_OK(env, napi_create_external(env, h, finalize_handle, nullptr, &ext));
+    return ext;
+}
+
+// groupRenderAsync(group, cols, rows, proj, view): ar_group_render_async
+napi_value js_group_render_async(napi_env env, napi_callback_info info) {
+    napi_value argv[5];
+    if (!get_args(env, info, 5, argv)) return nullptr;
+    ar_group *g = get_group(env, argv[0]);
+    if (!g) return nullptr;
+    void *p, *v;
+    size_t np, nv;
+    if (!get_typed(env, argv[3], napi_float32_array, &p, &np, false) || !get_typed(env, argv[4], napi_float32_array, &v, &nv, false)) return nullptr;
+    if (np != 16 || nv != 16) { napi_throw_range_error(env, nullptr, "groupRenderAsync: two Float32Array(16) expected"); return nullptr; }
+    if (ar_group_render_async(g, get_i32(env, argv[1]), get_i32(env, argv[2]), static_cast<const float *>(p), static_cast<const float *>(v)))
+        return throw_group(env, g, "ar_group_render_async");
+    return nullptr;
+}
+
+napi_value js_group_sync(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    ar_group *g = get_group(env, argv[0]);
+    if (!g) return nullptr;
+    if (ar_group_sync(g)) return throw_group(env, g, "ar_group_sync");
+    return nullptr;
+}
+
+napi_value js_group_frames_gathered(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return nullptr;
+    ar_group *g = get_group(env, argv[0]);
+    if (!g) return nullptr;
+    napi_value out;
+    napi_create_int32(env, ar_group_frames_gathered(g), &out);
+    return out;
+}
+
+// groupRead(group, member, frame, outAscii Uint8Array(cols*rows)): ar_group_read (the caller sizes the array to the last grid)
+napi_value js_group_read(napi_env env, napi_callback_info info) {
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv)) return nullptr;
+    ar_group *g = get_group(env, argv[0]);
+    if (!g) return nullptr;
+    void *out;
+    size_t n;
+    if (!get_typed(env, argv[3], napi_uint8_array, &out, &n, false)) return nullptr;
+    if (ar_group_read(g, get_i32(env, argv[1]), get_i32(env, argv[2]), static_cast<uint8_t *>(out))) return throw_group(env, g, "ar_group_read");
+    return nullptr;
+}
+
 napi_value init(napi_env env, napi_value exports) {
     const napi_property_descriptor props[] = {
         {"create", nullptr, js_create, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
@@ -811,6 +943,14 @@ napi_value init(napi_env env, napi_value exports) {
         {"quantizeColors", nullptr, js_quantize_colors, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"present", nullptr, js_present, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"updatePositions", nullptr, js_update_positions, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"stripRows", nullptr, js_strip_rows, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"groupCreate", nullptr, js_group_create, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"groupDestroy", nullptr, js_group_destroy, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"groupCtx", nullptr, js_group_ctx, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"groupRenderAsync", nullptr, js_group_render_async, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"groupSync", nullptr, js_group_sync, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"groupFramesGathered", nullptr, js_group_frames_gathered, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"groupRead", nullptr, js_group_read, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"renderAsync", nullptr, js_render_async, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"readAsync", nullptr, js_read_async, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"wait", nullptr, js_wait, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

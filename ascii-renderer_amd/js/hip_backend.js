@@ -324,7 +324,8 @@ export class HipRasterBackend {
   constructor(opts) {
     this.name = 'hip';
     this._device = (opts && opts.device) | 0;
-    this._h = null;
+    this._h = (opts && opts.nativeHandle) || null;      // a member of a group: the group owns the native context
+    this._borrowed = !!this._h;
     this._scene = null;
     this._hasGeometry = false;
     this._width = 0; this._height = 0;
@@ -367,7 +368,7 @@ export class HipRasterBackend {
   }
 
   dispose() {
-    if (this._h) native().destroy(this._h);   // waits for frames in flight
+    if (this._h && !this._borrowed) native().destroy(this._h);   // waits for frames in flight
     this._h = null;
     this._lastTopDown = null;
     this._own = null;
@@ -581,5 +582,64 @@ export class HipRasterBackend {
     this._ensure();
     const c = native().frameCounters(this._h);
     return { triangles: c[0], mediumRecords: c[1], largeRecords: c[2], binEntries: c[3], poolOverflow: c[4], tiled: c[5] };
+  }
+}
+
+/* ------------------------------ several GPUs -------------------------------- */
+// One frame on several GPUs of this machine, from one Node process (ar_group_*): the rows are cut into one strip per
+// device, each device renders its strip from its own copy of the scene on a native host thread, and every `batch` frames
+// RCCL all-gathers combine the ASCII strips, after which every device holds every frame of the batch.  The reference has
+// one GPU behind its router (js/gpu_renderer.js:92-95); this is the build's scaling layer for its hot path.
+//   const group = new HipRasterGroup({ devices: [0, 1, 2, 3], batch: 16 });
+//   group.setScene(scene);                       // every member, through the ordinary backend
+//   group.renderAsync(t, { cols, rows });        // live camera, returns at once
+//   group.sync(); group.read(frame)              // Uint8Array(cols * rows) of ASCII codes
+export class HipRasterGroup {
+  constructor(opts) {
+    const devices = (opts && opts.devices) || [0];
+    this.batch = Math.max(1, ((opts && opts.batch) | 0) || 16);
+    this._g = native().groupCreate(Int32Array.from(devices), this.batch);
+    this.members = devices.map((d, i) => new HipRasterBackend({ device: d, nativeHandle: native().groupCtx(this._g, i) }));
+    this.cols = 0; this.rows = 0;
+  }
+
+  static stripRows(rows, nStrips, strip) { return native().stripRows(rows | 0, nStrips | 0, strip | 0); }
+
+  setScene(scene) { for (const m of this.members) m.setScene(scene); }
+
+  // One frame with the live camera (js/camera.js) on every member; lights and ASCII parameters as render() uploads them.
+  renderAsync(timeSec, appState) {
+    const w = ((appState && appState.cols) | 0) || (config.VIRTUAL_GRID_WIDTH | 0) || 1;
+    const h = ((appState && appState.rows) | 0) || (config.VIRTUAL_GRID_HEIGHT | 0) || 1;
+    if (!this.members[0]._hasGeometry) return false;
+    if (!this._uniformsSent) {        // (scene-level uniforms: the members are idle now)
+      for (const m of this.members) m._uploadFrameState(w, h, appState);
+      this._uniformsSent = true;
+    }
+    const cam = { pos: LiveCamera.pos, yaw: LiveCamera.yaw, pitch: LiveCamera.pitch };
+    const mats = cameraMatrices(cam, w, h);
+    native().groupRenderAsync(this._g, w, h, mats.proj, mats.view);
+    this.cols = w; this.rows = h;
+    return true;
+  }
+
+  // Gathers what is left of the current batch and waits; lights / ASCII parameters are sent again with the next frame.
+  sync() { native().groupSync(this._g); this._uniformsSent = false; }
+
+  get framesGathered() { return native().groupFramesGathered(this._g); }
+
+  // ASCII grid of frame `frame` (0 = oldest) of the last gathered batch as member `member` holds it (call sync() first).
+  read(frame, member, out) {
+    const grid = out || new Uint8Array(this.cols * this.rows);
+    if (grid.length !== this.cols * this.rows) throw new Error('HipRasterGroup.read: array does not match the grid');
+    native().groupRead(this._g, member | 0, frame | 0, grid);
+    return grid;
+  }
+
+  dispose() {
+    if (!this._g) return;
+    for (const m of this.members) m.dispose();
+    native().groupDestroy(this._g);
+    this._g = null;
   }
 }

@@ -7,13 +7,19 @@ import torch.distributed as dist
 
 
 def strip_bounds(rows, world, rank):
-    """Rows [row0, row1) of rank `rank`: equal-height bands, as the all-gather needs equal sizes."""
-    if world <= 0 or not 0 <= rank < world:
+    """Rows [row0, row1) of rank `rank` when `rows` rows are cut into `world` bands: heights differ by at most one row
+    (the first rows % world bands are the taller ones), so any number of rows goes with any number of ranks - the
+    arithmetic of ar_strip_rows.  The all-gather moves slots of the tallest band's height (band_height)."""
+    if world <= 0 or not 0 <= rank < world or rows < 0:
         raise ValueError("bad rank %d of %d" % (rank, world))
-    if rows % world:
-        raise ValueError("rows (%d) must divide evenly over %d ranks" % (rows, world))
-    h = rows // world
-    return rank * h, (rank + 1) * h
+    base, rem = divmod(rows, world)
+    row0 = rank * base + min(rank, rem)
+    return row0, row0 + base + (1 if rank < rem else 0)
+
+
+def band_height(rows, world):
+    """Rows of the tallest band: the slot height every rank contributes to the all-gather."""
+    return (rows + world - 1) // world
 
 
 class _DeviceArray:
@@ -54,8 +60,9 @@ class StripBatcher:
 
     `device` tensors live wherever the bands live (HBM with RCCL, host memory with gloo in the tests)."""
 
-    def __init__(self, band_rows, cols, batch, device, before_gather=None, after_gather=None, rings=2):
-        """before_gather: called right before each all-gather, to make the gathering stream wait for the frames
+    def __init__(self, band_rows, cols, batch, device, before_gather=None, after_gather=None, rings=2, rows=None):
+        """band_rows: rows of a slot - this rank's band when the frame divides evenly, band_height(rows, world) otherwise,
+        with `rows` (the frame's) given so that frame() can cut the padding out again.  before_gather: called right before each all-gather, to make the gathering stream wait for the frames
         that filled the ring.  after_gather: makes the frames enqueued from then on wait for the gathers
         enqueued so far (stream-ordered, no host wait); with one ring it is called right after each gather, with
         more it is called before the next gather is enqueued - the frames that follow reuse the ring of an
@@ -63,6 +70,9 @@ class StripBatcher:
         self.before_gather, self.after_gather = before_gather, after_gather
         self.world = dist.get_world_size()
         self.batch, self.h, self.cols, self.rings = int(batch), int(band_rows), int(cols), max(1, int(rings))
+        self.rows = self.world * self.h if rows is None else int(rows)
+        if band_height(self.rows, self.world) != self.h:
+            raise ValueError("slots of %d rows do not fit %d rows over %d ranks" % (self.h, self.rows, self.world))
         self.ring = torch.empty((self.rings, self.batch, self.h, self.cols), dtype=torch.uint8, device=device)
         self.out = torch.empty((self.rings, self.world, self.batch, self.h, self.cols), dtype=torch.uint8, device=device)
         self.cur = 0           # ring being filled
@@ -71,8 +81,9 @@ class StripBatcher:
         self.gathered = 0      # frames held by out[last]
 
     def push(self, band):
-        """Copies one frame's band into the ring (stream-ordered on the current stream); gathers when full."""
-        self.ring[self.cur, self.filled].copy_(band)
+        """Copies one frame's band (its own rows; shorter than the slot for the lower ranks of an uneven cut) into the
+        ring (stream-ordered on the current stream); gathers when full."""
+        self.ring[self.cur, self.filled, :band.shape[0]].copy_(band)
         self.filled += 1
         if self.filled == self.batch:
             self.flush()
@@ -101,7 +112,13 @@ class StripBatcher:
         self.cur = (self.cur + 1) % self.rings
 
     def frame(self, k):
-        """Full grid [world * band_rows, cols] of frame k of the last gathered batch."""
+        """Full grid [rows, cols] of frame k of the last gathered batch (slot padding of an uneven cut removed)."""
         if not 0 <= k < self.gathered:
             raise IndexError("frame %d of a batch of %d" % (k, self.gathered))
-        return self.out[self.last][:, k].reshape(self.world * self.h, self.cols)
+        if self.rows == self.world * self.h:
+            return self.out[self.last][:, k].reshape(self.world * self.h, self.cols)
+        bands = []
+        for r in range(self.world):
+            row0, row1 = strip_bounds(self.rows, self.world, r)
+            bands.append(self.out[self.last][r, k, :row1 - row0])
+        return torch.cat(bands, dim=0)

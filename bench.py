@@ -59,6 +59,9 @@ def parse_args(argv=None):
     ap.add_argument("--gather-batch", type=int, default=16, help="frames per RCCL all-gather (multi-GPU runs)")
     ap.add_argument("--force-gather", action="store_true",
                     help="take the strip + all-gather path even with one rank (rehearsal of the multi-GPU loop on one GPU)")
+    ap.add_argument("--native-gather", action="store_true",
+                    help="one process for all --gpus devices: the library's own group (a host thread and a context per device, "
+                         "RCCL all-gathers inside the library) instead of one torch.distributed rank per GPU")
     ap.add_argument("--dry", action="store_true",
                     help="launcher rehearsal without a GPU: the ranks meet over gloo, time nothing and print the line's skeleton")
     return ap.parse_args(argv)
@@ -139,12 +142,13 @@ def dry_run(args, world, rank):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    native = args.native_gather and not args.dry
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not native:
         return launch_ranks(args, argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    if world != (1 if native else args.gpus):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.dry:
         return dry_run(args, world, rank)
@@ -163,21 +167,30 @@ def main(argv=None):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    gather = world > 1 or args.force_gather
-    if gather:
+    gather = world > 1 or args.force_gather or native
+    if gather and not native:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         try:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         except TypeError:                                  # older torch: no device_id argument
             dist.init_process_group("nccl", rank=rank, world_size=world)
-    ranks_seen = dist.get_world_size() if gather else 1
+    ranks_seen = args.gpus if native else (dist.get_world_size() if gather else 1)
+    n_strips = args.gpus if native else world
 
     mg = importlib.import_module("ascii-renderer_amd.multigpu")
     host = importlib.import_module("ascii-renderer_amd.host")
     sc = ar.scenes.random_scene(args.tris, args.cols, args.rows)
-    R = ar.Renderer(local_rank)
-    ar.scenes.upload(R, sc)
+    G = None
+    if native:
+        # the library's own group: device i renders strip i on a host thread of its own; this process only posts frames
+        G = ar.Group(list(range(args.gpus)), max(1, args.gather_batch))
+        for member in G.members:
+            ar.scenes.upload(member, sc)
+        R = G.members[0]
+    else:
+        R = ar.Renderer(local_rank)
+        ar.scenes.upload(R, sc)
     # the frame's camera: the workload's, turned by a yaw within +-YAW_JITTER that changes every frame
     cams = []
     for k in range(N_CAMERAS):
@@ -185,9 +198,9 @@ def main(argv=None):
         cam["yaw"] = cam["yaw"] + YAW_JITTER * math.sin(2.0 * math.pi * k / N_CAMERAS)
         cams.append(R.prepare_camera(*host.camera_matrices(cam, args.cols, args.rows, 1.0)))
     frame_no = [0]
-    row0, row1 = mg.strip_bounds(args.rows, world, rank)
+    row0, row1 = mg.strip_bounds(args.rows, n_strips, rank)
     ts = None
-    if gather:
+    if gather and not native:
         R.set_strip(row0, row1)
         torch.cuda.set_stream(torch.cuda.Stream())         # a real stream handle (the default stream's is 0)
         ts = torch.cuda.current_stream().cuda_stream
@@ -196,10 +209,10 @@ def main(argv=None):
         # two rings in rotation: the gather of one waits (on its stream) for the frames that filled it while the next
         # frames already fill the other; frames wait for a gather only when they come back to its ring, by which
         # time it is long over: two stream-ordered hand-overs per batch, no host waits, no pipeline drain
-        return mg.StripBatcher(row1 - row0, args.cols, max(1, batch), "cuda",
+        return mg.StripBatcher(mg.band_height(args.rows, world), args.cols, max(1, batch), "cuda", rows=args.rows,
                                before_gather=lambda: R.stream_wait_frame(ts), after_gather=lambda: R.frame_wait_stream(ts))
 
-    batcher = make_batcher(args.gather_batch) if gather else None
+    batcher = make_batcher(args.gather_batch) if (gather and not native) else None
     R.render_async(args.cols, args.rows)
     R.sync()
     # Multi-GPU loop: frames overlap on the renderer's own streams (three in flight) and write their ASCII
@@ -207,6 +220,10 @@ def main(argv=None):
     # the ranks' rings.  Per frame the host sets the camera and launches the frame's kernels.
 
     def step(b=None):
+        if b is G and G is not None:
+            G.render_async(args.cols, args.rows, cams[frame_no[0] % N_CAMERAS])
+            frame_no[0] += 1
+            return
         R.set_camera_prepared(cams[frame_no[0] % N_CAMERAS])
         frame_no[0] += 1
         if b is None:
@@ -217,11 +234,14 @@ def main(argv=None):
             b.advance()
 
     def fence(b=None):
+        if b is G and G is not None:
+            G.sync()
+            return
         if b is not None:
             b.flush()
         R.sync()
         torch.cuda.synchronize()
-        if gather:
+        if gather and not native:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -252,6 +272,8 @@ def main(argv=None):
         med = dts[len(dts) // 2] if len(dts) % 2 else 0.5 * (dts[len(dts) // 2 - 1] + dts[len(dts) // 2])
         return med / per_round, len(dts), per_round
 
+    if native:
+        batcher = G
     for _ in range(args.warmup):
         step(batcher)
     fence(batcher)
@@ -260,7 +282,19 @@ def main(argv=None):
 
     extras = {}
     gather_ok = None
-    if gather:
+    if native:
+        # the gathered grid of the last frame, as every device holds it, must be the full frame
+        last = G.frames_gathered() - 1
+        got = [G.read(last, member) for member in range(args.gpus)]
+        R.set_strip(0, 0)
+        R.set_ascii_target(None)
+        R.set_camera_prepared(cams[(frame_no[0] - 1) % N_CAMERAS])
+        full = R.render(args.cols, args.rows)["ascii"]
+        gather_ok = bool(last >= 0 and all(np.array_equal(g, full) for g in got))
+        if not gather_ok:
+            print("the group's gathered ASCII grid differs from a full-frame render", file=sys.stderr, flush=True)
+        R.set_strip(row0, row1)
+    elif gather:
         # the gathered grid of the last frame must be the full frame: compare with this rank's own full render
         torch.cuda.synchronize()
         R.set_strip(0, 0)
@@ -344,6 +378,8 @@ def main(argv=None):
                                   "4k_pageable": quantize_rate(3840, 2160, False), "4k_pinned": quantize_rate(3840, 2160, True)}
 
     if rank == 0:
+        if native:
+            R.set_ascii_target(None)
         cells = args.cols * (row1 - row0)
         entries = counters["bin_records"]
         per_launch_bytes = {                             # algorithmic bytes one launch must move
@@ -394,13 +430,14 @@ def main(argv=None):
         line = {
             "metric": "frames/sec at 1920x1080 cell grid, 1M tris", "value": fps, "unit": "frames/s",
             "mtri_per_s": fps * args.tris / 1e6,
-            "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "rounds": rounds,
+            "n_gpus": args.gpus, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "rounds": rounds,
             "frames_per_round": frames_per_round, "ms_per_step": 1e3 * frame_s,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32+f64",
             "data": "synthetic",
             "config": {"workload": "random mesh mulberry32(0xA5C11), %d tris, %dx%d cells, camera at origin with a per-frame yaw "
                                    "jitter of +-%.2f rad, default lights, modal smoothing on" % (args.tris, args.cols, args.rows, YAW_JITTER),
-                       "partition": "1 GPU" if not gather else "%d row strips, RCCL all-gather of the ASCII strips every %d frames" % (world, max(1, args.gather_batch)),
+                       "partition": "1 GPU" if not gather else "%d row strips, RCCL all-gather of the ASCII strips every %d frames%s"
+                                    % (n_strips, max(1, args.gather_batch), " (one process, the library's group)" if native else ""),
                        "algorithmic_bytes_per_frame": ar.scenes.algorithmic_bytes(args.tris, args.cols, args.rows),
                        "reference_layout_hbm_frac": ar.scenes.algorithmic_bytes(args.tris, args.cols, args.rows) * fps / 1e9 / HBM_PEAK_GBPS,
                        "layout_bytes_per_frame": layout_bytes,
@@ -442,8 +479,11 @@ def main(argv=None):
                 "where": "reference code imported under Node 12, 1 core, in the build container; random RGBA grid",
                 "gpu_twin": "ar_quantize, see quantize_fps"}
         print(json.dumps(line), file=result_out, flush=True)
-    R.close()
-    if gather:
+    if G is not None:
+        G.close()
+    else:
+        R.close()
+    if gather and not native:
         dist.barrier()
         dist.destroy_process_group()
     return 0

@@ -315,6 +315,41 @@ int ar_frame_counters(ar_ctx *ctx, uint32_t out[8]);
 #define AR_OPT_FOLD_SCAN 6
 int ar_set_option(ar_ctx *ctx, int option, long long value);
 
+/* ---- several GPUs in one process ------------------------------------------------------------------------
+ * The reference drives one GPU (js/gpu_renderer.js:92-95).  A group renders one frame on n GPUs: the rows are cut into
+ * n strips (ar_strip_rows), device i renders strip i from its own copy of the scene on a host thread of its own, and
+ * every `batch` frames one RCCL all-gather per device combines the ASCII strips, after which every device holds every
+ * frame of the batch.  No other host language is needed for it than the one that calls this C ABI.
+ *
+ *   ar_strip_rows      rows [row0, row1) of strip `strip` when `rows` rows are cut into n_strips: heights differ by at most
+ *                      one (the first rows % n_strips strips are the taller ones), so any count divides; plain arithmetic,
+ *                      needs no GPU.
+ *   ar_group_create    a context per device of device_ids[0..n) (each at most once), an RCCL communicator over them (RCCL is
+ *                      loaded at the first call) and a worker thread per device.  NULL on failure (ar_group_last_error(NULL)).
+ *   ar_group_ctx       member i's context, for the per-scene calls - ar_set_mesh*, ar_set_lights, ar_set_ascii, ar_set_model,
+ *                      ar_set_mesh_uv, ar_set_texture, ar_set_option - which the caller makes on every member, and only while
+ *                      the group is idle (before the first frame or after ar_group_sync).  The group itself sets each member's
+ *                      strip, ASCII target and camera per frame.
+ *   ar_group_render_async  enqueues one frame of cols x rows cells with the given camera (as ar_set_camera takes it) on every
+ *                      member and returns at once; the members' threads issue the launches.  The first frame of a new grid
+ *                      size waits for the frames before it and allocates the gather rings.
+ *   ar_group_sync      gathers what is left of the current batch and waits for everything; reports the first failure of
+ *                      any member since the last call.
+ *   ar_group_frames_gathered  frames held by the last completed gather (batch, or fewer after ar_group_sync cut one short).
+ *   ar_group_read      after a sync: the whole ASCII grid (cols*rows codes, row 0 = top) of frame `frame` (0 = oldest) of the
+ *                      last gathered batch, assembled from the strips member `member` received - every member holds them all. */
+typedef struct ar_group ar_group;
+int ar_strip_rows(int rows, int n_strips, int strip, int *row0, int *row1);
+ar_group *ar_group_create(int n, const int *device_ids, int batch);
+void ar_group_destroy(ar_group *group);
+const char *ar_group_last_error(ar_group *group);
+int ar_group_size(ar_group *group);
+ar_ctx *ar_group_ctx(ar_group *group, int member);
+int ar_group_render_async(ar_group *group, int cols, int rows, const float proj[16], const float view[16]);
+int ar_group_sync(ar_group *group);
+int ar_group_frames_gathered(ar_group *group);
+int ar_group_read(ar_group *group, int member, int frame, uint8_t *ascii);
+
 #ifdef __cplusplus
 }
 #endif

@@ -218,6 +218,30 @@ const dump = (name, ta) => fs.writeFileSync(path.join(outDir, name), Buffer.from
     fl.dispose();
   }
 
+  // several GPUs from Node (here: a group of the one device there is): strips, native worker threads, RCCL all-gathers
+  {
+    const hb = await import(path.join(JS, 'hip_backend.js'));
+    const [a0, a1] = hb.HipRasterGroup.stripRows(1080, 7, 2);
+    if (a0 !== 310 || a1 !== 464) throw new Error('stripRows(1080, 7, 2) should be [310, 464]');
+    const group = new hb.HipRasterGroup({ devices: [0], batch: 2 });
+    group.setScene(sceneApi.meshScene(ico, { lights }));
+    const cols = 640, rows = 360;
+    for (let k = 0; k < 3; k++) {
+      const c = meta.burst.cams[k];
+      setCamera(c.pos, c.yaw, c.pitch);
+      if (!group.renderAsync(k / 60, { cols, rows })) throw new Error('group.renderAsync should draw');
+      if (k === 1) {                       // a full batch of two: gathered without a flush
+        group.sync();
+        if (group.framesGathered !== 2) throw new Error('two frames should have been gathered');
+        dump('group0.ascii', group.read(0, 0)); dump('group1.ascii', group.read(1, 0));
+      }
+    }
+    group.sync();
+    if (group.framesGathered !== 1) throw new Error('one frame should be left in the last batch');
+    dump('group2.ascii', group.read(0, 0));
+    group.dispose(); group.dispose();
+  }
+
   // the ray backend under the reference's names: router -> HipRaytraceBackend -> ar_rt_set_scene / ar_rt_render
   {
     const rtRef = JSON.parse(fs.readFileSync(path.join(here, '..', 'golden', 'ref_raytrace_uniforms.json'), 'utf8'));

@@ -674,6 +674,49 @@ def test_ascii_target_ring_with_an_odd_row_length(pkg, oracle):
         r.close()
 
 
+def test_group_of_one_device_gathers_the_full_frame(pkg, oracle):
+    """ar_group_*: the library's own multi-GPU loop (a context and a host thread per device, strips, RCCL all-gathers in
+    batches over two rings) on the one device there is here: every frame of a run - batches full and cut short, a grid
+    whose rows would not divide over more devices, a camera per frame - comes back from the gather as the oracle's frame."""
+    cols, rows = 333, 77
+    sc = pkg.scenes.random_scene(30_000, cols, rows, mesh_grid=(cols, rows))
+    cams = [{"pos": (0.0, 0.0, 0.0), "yaw": 0.02 * k, "pitch": 0.01 * k} for k in range(7)]
+    mats = [pkg.host.camera_matrices(c, cols, rows, 1.0) for c in cams]
+    want = []
+    for proj, view in mats:
+        rgba, _d, _i = oracle.render(sc["vbo"], sc["idx"], proj, view, sc["lights"], cols, rows)
+        want.append(oracle.quantize(rgba, cols, rows, pkg.scenes.DEFAULT_RAMP, 1, 2, 12))
+    with pytest.raises(pkg.AsciiRastError):
+        pkg.Group([0, 0])                                   # a device named twice
+    G = pkg.Group([0], batch=3)
+    try:
+        assert G.n == 1 and G.frames_gathered() == 0
+        pkg.scenes.upload(G.members[0], sc)
+        prepared = [pkg.Renderer.prepare_camera(p, v) for p, v in mats]
+        for k in range(7):                                  # two full batches and one frame left over
+            G.render_async(cols, rows, prepared[k])
+        G.sync()
+        assert G.frames_gathered() == 1
+        assert np.array_equal(G.read(0), want[6])
+        for k in range(3):                                  # exactly one batch: gathered without a flush
+            G.render_async(cols, rows, prepared[k])
+        G.sync()
+        assert G.frames_gathered() == 3
+        for k in range(3):
+            assert np.array_equal(G.read(k), want[k]), k
+        with pytest.raises(pkg.AsciiRastError):
+            G.read(3)
+        # another grid size: the rings follow
+        c2, r2 = 96, 36
+        proj, view = pkg.host.camera_matrices(cams[1], c2, r2, 1.0)
+        rgba, _d, _i = oracle.render(sc["vbo"], sc["idx"], proj, view, sc["lights"], c2, r2)
+        G.render_async(c2, r2, pkg.Renderer.prepare_camera(proj, view))
+        G.sync()
+        assert np.array_equal(G.read(0), oracle.quantize(rgba, c2, r2, pkg.scenes.DEFAULT_RAMP, 1, 2, 12))
+    finally:
+        G.close()
+
+
 def test_many_tiles_take_the_direct_path(pkg, oracle):
     """More than 8000 tiles (here 8192 x 2048 cells = 8192 tiles): the library falls back to the direct path."""
     r = pkg.Renderer(0)

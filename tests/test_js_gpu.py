@@ -129,6 +129,13 @@ def test_node_harness_frames_match_oracle(pkg, oracle, tmp_path, rt_uniforms_of)
     strip = np.fromfile(tmp_path / "burst_strip.ascii", dtype=np.uint8).reshape(rows, cols)
     assert np.array_equal(strip[100:200], asc[100:200])
 
+    # the group of devices driven from Node: the first three burst cameras again, gathered in batches of two
+    for k in range(3):
+        proj, view = pkg.host.camera_matrices(b["cams"][k], cols, rows, b["pixelAspect"])
+        rgba_k, _d, _i = oracle.render(vbo, idx, proj, view, lights, cols, rows)
+        assert np.array_equal(np.fromfile(tmp_path / ("group%d.ascii" % k), dtype=np.uint8).reshape(rows, cols),
+                              oracle.quantize(rgba_k, cols, rows, ramp, 1, 2, 12)), k
+
     # the ray backend through the router: same image as the oracle fed with the reference's recorded uniforms
     rtm = meta["raytrace"]
     with open(os.path.join(ROOT, "tests", "golden", "ref_raytrace_uniforms.json")) as fh:

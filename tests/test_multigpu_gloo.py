@@ -63,6 +63,17 @@ def _worker(rank, world, port, tmp):
             sb.advance()
             ok = ok and log[mark:] == want
             ok = ok and np.array_equal(sb.frame(0).numpy(), frames[k])
+    # a frame whose rows do not divide over the ranks: bands differ by a row, slots are as tall as the tallest
+    rows_u = 45 if world == 2 else 46
+    grid = np.random.default_rng(11).integers(32, 127, size=(3, rows_u, cols), dtype=np.uint8)
+    r0, r1 = mg.strip_bounds(rows_u, world, rank)
+    sb = mg.StripBatcher(mg.band_height(rows_u, world), cols, 2, "cpu", rows=rows_u)
+    for k in range(2):
+        sb.push(torch.from_numpy(grid[k, r0:r1].copy()))
+    ok = ok and sb.gathered == 2 and all(np.array_equal(sb.frame(k).numpy(), grid[k]) for k in range(2))
+    sb.push(torch.from_numpy(grid[2, r0:r1].copy()))
+    sb.flush()
+    ok = ok and sb.gathered == 1 and np.array_equal(sb.frame(0).numpy(), grid[2])
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
@@ -82,7 +93,30 @@ def test_strip_bounds(pkg):
     mg = importlib.import_module("ascii-renderer_amd.multigpu")
     assert [mg.strip_bounds(1080, 8, r) for r in range(8)] == [(135 * r, 135 * (r + 1)) for r in range(8)]
     assert mg.strip_bounds(2160, 1, 0) == (0, 2160)
-    with pytest.raises(ValueError):
-        mg.strip_bounds(1080, 7, 0)
+    assert [mg.strip_bounds(1080, 7, r) for r in range(7)] == [(0, 155), (155, 310), (310, 464), (464, 618), (618, 772), (772, 926), (926, 1080)]
     with pytest.raises(ValueError):
         mg.strip_bounds(1080, 2, 2)
+
+
+def test_strips_of_any_row_count_tile_the_frame():
+    """The partition arithmetic, Python twin against the library's ar_strip_rows (no GPU involved): strips are contiguous,
+    cover every row once, differ by at most one row - also where the rows do not divide (1080 over 7, 36 over 8) and
+    where there are more strips than rows."""
+    sys.path.insert(0, ROOT)
+    ar = importlib.import_module("ascii-renderer_amd")
+    mg = importlib.import_module("ascii-renderer_amd.multigpu")
+    for rows, world in [(1080, 7), (36, 8), (1080, 8), (2160, 8), (45, 2), (46, 4), (3, 8), (1, 1), (0, 4), (1081, 64)]:
+        edge = 0
+        heights = []
+        for rank in range(world):
+            r0, r1 = mg.strip_bounds(rows, world, rank)
+            assert (r0, r1) == ar.strip_rows(rows, world, rank), (rows, world, rank)
+            assert r0 == edge and r1 >= r0
+            heights.append(r1 - r0)
+            edge = r1
+        assert edge == rows and max(heights) - min(heights) <= 1 and max(heights) == mg.band_height(rows, world)
+        assert heights == sorted(heights, reverse=True)          # the taller strips come first
+    with pytest.raises(ValueError):
+        ar.strip_rows(10, 0, 0)
+    with pytest.raises(ValueError):
+        mg.strip_bounds(10, 4, 4)
