@@ -19,6 +19,7 @@ EXPORTS = [
     "ar_frame_counters", "ar_set_option", "ar_set_mesh_uv", "ar_set_texture", "ar_set_mesh_indexed", "ar_read_mesh",
     "ar_rt_set_scene", "ar_rt_render", "ar_rt_render_async", "ar_quantize_static", "ar_set_model",
     "ar_read_async", "ar_wait", "ar_poll", "ar_update_positions",
+    "ar_render_batch_async", "ar_read_batch", "ar_batch_device_buffer",
     "ar_strip_rows", "ar_group_create", "ar_group_destroy", "ar_group_last_error", "ar_group_size", "ar_group_ctx",
     "ar_group_render_async", "ar_group_sync", "ar_group_frames_gathered", "ar_group_read",
 ]
@@ -113,6 +114,12 @@ def load_library():
     L.ar_group_read.argtypes = [vp, ctypes.c_int, ctypes.c_int, _u8p]
     for name in ("ar_strip_rows", "ar_group_size", "ar_group_render_async", "ar_group_sync", "ar_group_frames_gathered", "ar_group_read"):
         getattr(L, name).restype = ctypes.c_int
+    L.ar_render_batch_async.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_size_t]
+    L.ar_render_batch_async.restype = ctypes.c_int
+    L.ar_read_batch.argtypes = [vp, ctypes.c_int, _u8p, _fp, _u8p, _u32p]
+    L.ar_read_batch.restype = ctypes.c_int
+    L.ar_batch_device_buffer.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    L.ar_batch_device_buffer.restype = vp
     L.ar_device_buffer.argtypes = [vp, ctypes.c_int]
     L.ar_device_buffer.restype = vp
     L.ar_stream.argtypes = [vp]
@@ -372,6 +379,38 @@ class Renderer:
             depth.ctypes.data_as(_fp) if depth is not None else None,
             ascii.ctypes.data_as(_u8p) if ascii is not None else None))
         self.cols, self.rows = int(cols), int(rows)
+
+    @staticmethod
+    def pack_cameras(cameras):
+        """[(proj, view), ...] -> float32 [n, 32] as ar_render_batch_async takes it."""
+        out = np.zeros((len(cameras), 32), dtype=np.float32)
+        for k, (proj, view) in enumerate(cameras):
+            out[k, :16] = np.asarray(proj, dtype=np.float32).reshape(-1)
+            out[k, 16:] = np.asarray(view, dtype=np.float32).reshape(-1)
+        return out
+
+    def render_batch_async(self, cols, rows, packed_cameras, ascii_stride=0):
+        """len(packed_cameras) frames in one chain of launches (packed_cameras: pack_cameras' array)."""
+        cams = packed_cameras
+        rc = self._L.ar_render_batch_async(self._h, int(cols), int(rows), int(cams.shape[0]), cams.ctypes.data_as(_fp), int(ascii_stride))
+        if rc:
+            self._check(rc)
+        self.cols, self.rows = int(cols), int(rows)
+
+    def read_batch(self, frame, want_ids=False, rgba=True, depth=True, ascii=True):
+        r, c = self.rows, self.cols
+        a_rgba = np.zeros((r, c, 4), dtype=np.uint8) if rgba else None
+        a_depth = np.zeros((r, c), dtype=np.float32) if depth else None
+        a_ascii = np.zeros((r, c), dtype=np.uint8) if ascii else None
+        a_ids = np.zeros((r, c), dtype=np.uint32) if want_ids else None
+        self._check(self._L.ar_read_batch(
+            self._h, int(frame),
+            a_rgba.ctypes.data_as(_u8p) if rgba else None, a_depth.ctypes.data_as(_fp) if depth else None,
+            a_ascii.ctypes.data_as(_u8p) if ascii else None, a_ids.ctypes.data_as(_u32p) if want_ids else None))
+        return {"rgba": a_rgba, "depth": a_depth, "ascii": a_ascii, "ids": a_ids}
+
+    def batch_device_buffer(self, which, frame):
+        return self._L.ar_batch_device_buffer(self._h, {"rgba": 0, "depth": 1, "ascii": 2}[which], int(frame))
 
     def read_async(self, rgba=None, depth=None, ascii=None, ids=None):
         """Queues copies of the last enqueued frame's planes into the given host arrays (page-locked ones from

@@ -133,6 +133,7 @@ void ar_destroy(ar_ctx *ctx) {
     for (auto &s : ctx->stamps) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
     free_targets(ctx);
+    for (int k = 0; k < kSets; k++) free_batch_set(ctx->batch[k]);
     (void)hipFree(ctx->d_vbo); (void)hipFree(ctx->d_idx);
     (void)hipFree(ctx->d_medium); (void)hipFree(ctx->d_large); (void)hipFree(ctx->d_counters);
     (void)hipFree(ctx->d_q_rgba); (void)hipFree(ctx->d_q_ascii); (void)hipFree(ctx->d_q_plane); (void)hipFree(ctx->d_q_colors);
@@ -382,6 +383,40 @@ int ar_set_strip(ar_ctx *ctx, int row0, int row1) {
 int ar_render_async(ar_ctx *ctx, int cols, int rows) {
     if (!ctx) return AR_E_ARG;
     return enqueue_frame(ctx, cols, rows, true);
+}
+
+int ar_render_batch_async(ar_ctx *ctx, int cols, int rows, int n_frames, const float *cameras, size_t ascii_stride) {
+    if (!ctx) return AR_E_ARG;
+    return enqueue_batch(ctx, cols, rows, n_frames, cameras, ascii_stride);
+}
+
+int ar_read_batch(ar_ctx *ctx, int frame, uint8_t *rgba, float *depth, uint8_t *ascii, uint32_t *ids) {
+    if (!ctx) return AR_E_ARG;
+    if (ctx->last_batch < 0 || frame < 0 || frame >= ctx->last_batch_frames)
+        return fail(ctx, AR_E_STATE, "ar_read_batch: frame %d of a last batch of %d", frame, ctx->last_batch < 0 ? 0 : ctx->last_batch_frames);
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = sync_streams(ctx);
+    if (rc) return rc;
+    const BatchSet &b = ctx->batch[ctx->last_batch];
+    const size_t n = size_t(ctx->batch_cols) * ctx->batch_rows, f = size_t(frame);
+    if (ids && !b.d_ids) return fail(ctx, AR_E_STATE, "ar_read_batch: ids wanted but ar_set_id_output was not on for the batch");
+    if (rgba) AR_HIP(ctx, hipMemcpy(rgba, b.d_rgba + f * n * 4, n * 4, hipMemcpyDeviceToHost));
+    if (depth) AR_HIP(ctx, hipMemcpy(depth, b.d_depth + f * n, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (ascii) AR_HIP(ctx, hipMemcpy(ascii, b.d_ascii + f * n, n, hipMemcpyDeviceToHost));
+    if (ids) AR_HIP(ctx, hipMemcpy(ids, b.d_ids + f * n, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+void *ar_batch_device_buffer(ar_ctx *ctx, int which, int frame) {
+    if (!ctx || ctx->last_batch < 0 || frame < 0 || frame >= ctx->last_batch_frames) return nullptr;
+    const BatchSet &b = ctx->batch[ctx->last_batch];
+    const size_t n = size_t(ctx->batch_cols) * ctx->batch_rows, f = size_t(frame);
+    switch (which) {
+        case 0: return b.d_rgba + f * n * 4;
+        case 1: return b.d_depth + f * n;
+        case 2: return b.d_ascii + f * n;
+        default: return nullptr;
+    }
 }
 
 int ar_sync(ar_ctx *ctx) {
@@ -960,8 +995,9 @@ int ar_set_option(ar_ctx *ctx, int option, long long value) {
             ctx->no_fold = value == 0;
             return 0;
         case AR_OPT_WORK_CLASSES:
-            if (value != 0 && value != 1) return fail(ctx, AR_E_ARG, "AR_OPT_WORK_CLASSES takes 0 or 1");
+            if (value < 0 || value > 3) return fail(ctx, AR_E_ARG, "AR_OPT_WORK_CLASSES takes 0 .. 3");
             ctx->no_classes = value == 0;
+            ctx->cls_area = value >= 2 ? int(value) - 1 : 0;
             return 0;
         default:
             return fail(ctx, AR_E_ARG, "unknown option %d", option);

@@ -162,8 +162,11 @@ __global__ __launch_bounds__(256) void k_ascii(FrameParams fp, const void *__res
 // side) is three aligned dwords per row: 3 * (2R + 1) LDS reads serve four cells, and the neighbours are
 // byte fields of registers.  Same Boyer-Moore order and vote rule as k_ascii (the plane holds no override cells,
 // so every neighbour votes).
-template <int R>
-__global__ __launch_bounds__(256) void k_ascii_plane(FrameParams fp, const uint8_t *__restrict__ src, uint8_t *__restrict__ ascii) {
+template <int R, bool BATCH>
+__global__ __launch_bounds__(256) void k_ascii_plane(FrameParams fp_one, const uint8_t *__restrict__ src, uint8_t *__restrict__ ascii,
+                                                     const FrameParams *__restrict__ fps, BatchStrides bs) {
+    const FrameParams &fp = BATCH ? fps[blockIdx.z] : fp_one;
+    if (BATCH) { src += size_t(blockIdx.z) * bs.cells; ascii += size_t(blockIdx.z) * bs.ascii; }
     constexpr int TWD = 34, TH = 8 + 2 * R;  // dwords per tile row: 4 bytes of left halo, 128 cells, 4 of right halo
     __shared__ uint32_t tile[TWD * TH];
     __shared__ uint8_t ramp[AR_MAX_RAMP];
@@ -255,9 +258,11 @@ __global__ __launch_bounds__(256) void k_ascii_plane(FrameParams fp, const uint8
 // cell with one in its window to the second step, which runs the shader's passes with the cell skipped, as the shader
 // does (ascii_pass_shader.js:98,125).  Overrides are sparse (a border, a line of text), so few cells take that road.
 constexpr int kPlaneOverride = 255;
-template <int R, bool OV>
-__global__ __launch_bounds__(256) void k_ascii_counts(FrameParams fp, const uint8_t *__restrict__ src, const uint32_t *__restrict__ rgba,
-                                                      uint8_t *__restrict__ ascii) {
+template <int R, bool OV, bool BATCH>
+__global__ __launch_bounds__(256) void k_ascii_counts(FrameParams fp_one, const uint8_t *__restrict__ src, const uint32_t *__restrict__ rgba,
+                                                      uint8_t *__restrict__ ascii, const FrameParams *__restrict__ fps, BatchStrides bs) {
+    const FrameParams &fp = BATCH ? fps[blockIdx.z] : fp_one;
+    if (BATCH) { src += size_t(blockIdx.z) * bs.cells; ascii += size_t(blockIdx.z) * bs.ascii; }
     constexpr int TWD = 34, TH = 8 + 2 * R;  // as k_ascii_plane: dwords per tile row (4 bytes of halo either side), tile rows
     constexpr int N = (2 * R + 1) * (2 * R + 1) - 1, NC = 4 + 2 * R;
     constexpr unsigned long long kOnes = 0x0041041041041041ull;  // bit 0 of each of the ten 6-bit fields
@@ -432,20 +437,36 @@ inline bool ascii_counts_domain(const FrameParams &fp) {
 // textured frames) and the counting kernel when the parameters allow, else the generic kernel straight from the grid.
 inline void launch_ascii_rgba(const FrameParams &fp, const uint32_t *rgba, uint8_t *plane, bool plane_ready, uint8_t *ascii, hipStream_t stream);
 
+// Smoothing of n frames' ramp-index planes in one launch (n = 1: the single frame of fp; else fps holds the n frames'
+// parameters and the planes lie bs.cells / bs.ascii bytes apart).
+inline void launch_ascii_planes(const FrameParams &fp, const uint8_t *plane, uint8_t *ascii, hipStream_t stream, int n,
+                                const FrameParams *fps, const BatchStrides &bs) {
+    const int radius = fp.mode_radius < 1 ? 1 : (fp.mode_radius > 3 ? 3 : fp.mode_radius);  // shader clamps to 1..3
+    const dim3 grid((fp.cols + 127) / 128, (fp.row1 - fp.row0 + 7) / 8, unsigned(n));
+    if (n > 1) {
+        if (ascii_counts_domain(fp)) {
+            if (radius == 1) k_ascii_counts<1, false, true><<<grid, 256, 0, stream>>>(fp, plane, nullptr, ascii, fps, bs);
+            else k_ascii_counts<2, false, true><<<grid, 256, 0, stream>>>(fp, plane, nullptr, ascii, fps, bs);
+        } else if (radius == 1) k_ascii_plane<1, true><<<grid, 256, 0, stream>>>(fp, plane, ascii, fps, bs);
+        else if (radius == 2) k_ascii_plane<2, true><<<grid, 256, 0, stream>>>(fp, plane, ascii, fps, bs);
+        else k_ascii_plane<3, true><<<grid, 256, 0, stream>>>(fp, plane, ascii, fps, bs);
+        return;
+    }
+    if (ascii_counts_domain(fp)) {
+        if (radius == 1) k_ascii_counts<1, false, false><<<grid, 256, 0, stream>>>(fp, plane, nullptr, ascii, nullptr, bs);
+        else k_ascii_counts<2, false, false><<<grid, 256, 0, stream>>>(fp, plane, nullptr, ascii, nullptr, bs);
+        return;
+    }
+    if (radius == 1) k_ascii_plane<1, false><<<grid, 256, 0, stream>>>(fp, plane, ascii, nullptr, bs);
+    else if (radius == 2) k_ascii_plane<2, false><<<grid, 256, 0, stream>>>(fp, plane, ascii, nullptr, bs);
+    else k_ascii_plane<3, false><<<grid, 256, 0, stream>>>(fp, plane, ascii, nullptr, bs);
+}
+
 template <bool FROM_RGBA>
 void launch_ascii(const FrameParams &fp, const void *src, uint8_t *ascii, hipStream_t stream) {
     const int radius = fp.mode_radius < 1 ? 1 : (fp.mode_radius > 3 ? 3 : fp.mode_radius);  // shader clamps to 1..3
     if constexpr (!FROM_RGBA) {
-        const dim3 grid((fp.cols + 127) / 128, (fp.row1 - fp.row0 + 7) / 8);
-        const uint8_t *plane = static_cast<const uint8_t *>(src);
-        if (ascii_counts_domain(fp)) {
-            if (radius == 1) k_ascii_counts<1, false><<<grid, 256, 0, stream>>>(fp, plane, nullptr, ascii);
-            else k_ascii_counts<2, false><<<grid, 256, 0, stream>>>(fp, plane, nullptr, ascii);
-            return;
-        }
-        if (radius == 1) k_ascii_plane<1><<<grid, 256, 0, stream>>>(fp, plane, ascii);
-        else if (radius == 2) k_ascii_plane<2><<<grid, 256, 0, stream>>>(fp, plane, ascii);
-        else k_ascii_plane<3><<<grid, 256, 0, stream>>>(fp, plane, ascii);
+        launch_ascii_planes(fp, static_cast<const uint8_t *>(src), ascii, stream, 1, nullptr, BatchStrides{});
     } else {
         const dim3 grid((fp.cols + 31) / 32, (fp.row1 - fp.row0 + 7) / 8);
         if (radius == 1) k_ascii<1, FROM_RGBA><<<grid, 256, 0, stream>>>(fp, src, ascii);
@@ -465,8 +486,8 @@ inline void launch_ascii_rgba(const FrameParams &fp, const uint32_t *rgba, uint8
         k_plane_from_rgba<<<unsigned((n + 255) / 256), 256, 0, stream>>>(fp, rgba, plane);
     }
     const dim3 grid((fp.cols + 127) / 128, (fp.row1 - fp.row0 + 7) / 8);
-    if (radius == 1) k_ascii_counts<1, true><<<grid, 256, 0, stream>>>(fp, plane, rgba, ascii);
-    else k_ascii_counts<2, true><<<grid, 256, 0, stream>>>(fp, plane, rgba, ascii);
+    if (radius == 1) k_ascii_counts<1, true, false><<<grid, 256, 0, stream>>>(fp, plane, rgba, ascii, nullptr, BatchStrides{});
+    else k_ascii_counts<2, true, false><<<grid, 256, 0, stream>>>(fp, plane, rgba, ascii, nullptr, BatchStrides{});
 }
 
 }  // namespace

@@ -10,6 +10,28 @@ thread_local char g_create_error[256] = "";
 
 constexpr int kTicketRing = 8;  // tickets per stream whose events are kept apart (older ones wait for a newer event of the same stream)
 
+constexpr int kMaxBatchFrames = 256;  // frames one ar_render_batch_async call takes
+
+// Buffers of a batch of frames rendered by one launch chain (ar_render_batch_async): everything a frame writes, n times
+// over, frame after frame.  There are kSets of these, used by consecutive batches in rotation like the buffer sets of
+// single frames, so that batches overlap on the frame streams the same way.
+struct BatchSet {
+    int frames = 0;                // frames the buffers hold
+    size_t cells = 0;              // cells per frame
+    size_t surv = 0, dircount = 0, dir_table = 0, entries = 0;  // per-frame sizes: survivor places, count-table words (+ totals), of which table, bin entries
+    bool ids = false;
+    uint2 *d_surv = nullptr; uint32_t *d_sid = nullptr, *d_surv_count = nullptr, *d_dircount = nullptr, *d_entries = nullptr;
+    BinState *d_state = nullptr;
+    uint64_t *d_vis = nullptr;
+    uint8_t *d_ridx = nullptr, *d_rgba = nullptr, *d_ascii = nullptr;
+    float *d_depth = nullptr;
+    uint32_t *d_ids = nullptr;
+    FrameParams *d_fps = nullptr, *h_fps = nullptr;  // the frames' parameters: device array, page-locked staging
+    hipEvent_t ev_params = nullptr;                  // the staging array has been copied (it may be rewritten)
+    bool params_pending = false;
+    bool blocksum_zero = false;    // the totals behind every frame's count table are zero
+};
+
 struct ar_ctx {
     int device = 0;
     hipStream_t stream = nullptr;   // stream of frames that do not overlap, of quantize / present and of copies: own_stream
@@ -55,6 +77,7 @@ struct ar_ctx {
     uint32_t pool_cap_option = 0;    // 0: sized from the triangle count
     int tile_shift_option = 0;       // 0: tile height chosen per frame; 3, 4, 5: fixed at 8, 16, 32 rows
     bool no_classes = false;         // AR_OPT_WORK_CLASSES 0: tile lists stay in entry order
+    int cls_area = 1;                // AR_OPT_WORK_CLASSES 1: rows, then width of the cell range; 2: rows, then area; 3: area, then rows
     bool no_fold = false;            // AR_OPT_FOLD_SCAN 0: k_binscan in every frame
     bool blocksum_zero[kSets] = {};  // the totals behind the count table of a set are zero (left so by a frame without k_binscan)
     float *d_tripos = nullptr;       // 9 planes x tripos_stride floats: triangle positions
@@ -85,6 +108,9 @@ struct ar_ctx {
     uint32_t *d_entries[kSets] = {};  // (2*triangle + sub, tile mask) entries grouped by bin
     uint32_t pool_cap = 0;
     BinState *d_state = nullptr;     // kSets blocks
+    BatchSet batch[kSets];           // ar_render_batch_async
+    uint32_t batch_no = 0;           // batches enqueued so far
+    int last_batch = -1, last_batch_frames = 0, batch_cols = 0, batch_rows = 0;  // set, frame count and grid of the most recent batch
     uint32_t frame = 0;              // tiled frames enqueued so far
     bool last_tiled = false;
     uint8_t *d_q_rgba = nullptr, *d_q_ascii = nullptr, *d_q_plane = nullptr;  // ar_quantize staging: grid, codes, ramp-index plane
@@ -262,21 +288,14 @@ bool ascii_target_misaligned(const ar_ctx *ctx, int cols) {
     return ctx->ascii_target && (cols & 3) == 0 && (reinterpret_cast<uintptr_t>(ctx->ascii_target) & 3u) != 0;
 }
 
-// Frames whose caller does not wait for them right away (may_overlap) run entirely on one of kSets frame
-// streams, frame f on stream f % kSets, and every buffer a frame writes exists kSets times: consecutive
-// frames share the GPU without a single cross-stream event (each of which costs the host about as much as
-// two kernel launches), and frame f + kSets follows frame f on the same stream, which is all the ordering
-// the reuse of a buffer set needs.
-int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
-    if (cols <= 0 || rows <= 0 || size_t(cols) * rows > (size_t(1) << 31))
-        return fail(ctx, AR_E_ARG, "ar_render: bad grid %d x %d", cols, rows);
-    if (ascii_target_misaligned(ctx, cols))
-        return fail(ctx, AR_E_ARG, "ar_render: the ASCII target must be 4-byte aligned when the row length (%d) is a multiple of four", cols);
-    AR_HIP(ctx, hipSetDevice(ctx->device));
-    int rc = ensure_targets(ctx, cols, rows);
-    if (rc) return rc;
-    if (ctx->n_tris == 0 || !ctx->d_vbo || !ctx->d_idx) return 0;  // raster.js:274: nothing to draw
+// What a frame of cols x rows cells looks like under the context's current state: fills fp (camera, strip, tile and bin
+// grids, entry format - everything but the buffer set and the scan mode) and tells which path it takes.
+struct FramePlan {
+    bool tiled = false, textured = false;
+    size_t nbins = 0, strip_cells = 0;
+};
 
+int plan_frame(ar_ctx *ctx, int cols, int rows, FramePlan &plan) {
     FrameParams &fp = ctx->fp;
     fp.cols = cols; fp.rows = rows;
     fp.hw = float(cols) * 0.5f; fp.hh = float(rows) * 0.5f;
@@ -301,12 +320,11 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
             for (int r = 0; r < 3; r++) fp.model[3 * c + r] = ctx->model[4 * c + r];
     }
     // texturing needs texel coordinates, an atlas, and more than one texel either way (shader_utils.js:94)
-    const bool textured = ctx->d_triuv && ctx->d_atlas && ctx->atlas_w > 1 && ctx->atlas_h > 1;
-    fp.tex_w = textured ? ctx->atlas_w : 0;
-    fp.tex_h = textured ? ctx->atlas_h : 0;
+    plan.textured = ctx->d_triuv && ctx->d_atlas && ctx->atlas_w > 1 && ctx->atlas_h > 1;
+    fp.tex_w = plan.textured ? ctx->atlas_w : 0;
+    fp.tex_h = plan.textured ? ctx->atlas_h : 0;
 
-    const size_t strip_cells = size_t(fp.yb - fp.ya) * cols;
-    const unsigned cell_blocks = unsigned((strip_cells + 255) / 256);
+    plan.strip_cells = size_t(fp.yb - fp.ya) * cols;
     fp.ntx = (cols + kTileW - 1) / kTileW;
     // tile height: 32 rows, halved while the frame has fewer tiles than two per compute unit (strips, small grids)
     fp.tshift = kTileShiftMax;
@@ -318,8 +336,47 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
     fp.nby = (fp.nty + (1 << fp.bshift) - 1) >> fp.bshift;
     const size_t nt = size_t(fp.ntx) * fp.nty;
     const size_t nbins = size_t(fp.nbx) * fp.nby;
-    const bool tiled = ctx->path == 0 && nt <= size_t(kMaxTiles) && nbins <= size_t(kMaxBins) && cols <= 65535 &&
+    plan.nbins = nbins;
+    plan.tiled = ctx->path == 0 && nt <= size_t(kMaxTiles) && nbins <= size_t(kMaxBins) && cols <= 65535 &&
                        rows <= 65535 && ctx->d_tripos && ctx->n_tris <= (kEntryLocMask >> 1) - 65536u;  // slots fit an entry
+    if (plan.tiled) {
+        // one triangle per k_setup lane and pass; more passes only beyond kMaxGroups workgroups
+        uint32_t chunk = (fp.n_tris + kMaxGroups - 1) / kMaxGroups;
+        chunk = (chunk + kSetupThreads - 1) / kSetupThreads * kSetupThreads;
+        fp.chunk = chunk;
+        fp.n_groups = (fp.n_tris + chunk - 1) / chunk;
+        fp.id_bits = 1;
+        while (fp.id_bits < kEntryMaskShift && (2ull * fp.n_tris - 1) >> fp.id_bits) fp.id_bits++;
+        fp.cls_bits = std::min(kEntryMaskShift - fp.id_bits, kMaxClassBits);
+        if (ctx->no_classes) fp.cls_bits = 0;
+        fp.cls_area = ctx->cls_area;
+        fp.fold_scan = (nbins <= size_t(kFoldScanBins) && !ctx->no_fold) ? 1 : 0;
+    }
+    return 0;
+}
+
+// Frames whose caller does not wait for them right away (may_overlap) run entirely on one of kSets frame
+// streams, frame f on stream f % kSets, and every buffer a frame writes exists kSets times: consecutive
+// frames share the GPU without a single cross-stream event (each of which costs the host about as much as
+// two kernel launches), and frame f + kSets follows frame f on the same stream, which is all the ordering
+// the reuse of a buffer set needs.
+int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
+    if (cols <= 0 || rows <= 0 || size_t(cols) * rows > (size_t(1) << 31))
+        return fail(ctx, AR_E_ARG, "ar_render: bad grid %d x %d", cols, rows);
+    if (ascii_target_misaligned(ctx, cols))
+        return fail(ctx, AR_E_ARG, "ar_render: the ASCII target must be 4-byte aligned when the row length (%d) is a multiple of four", cols);
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_targets(ctx, cols, rows);
+    if (rc) return rc;
+    if (ctx->n_tris == 0 || !ctx->d_vbo || !ctx->d_idx) return 0;  // raster.js:274: nothing to draw
+
+    FramePlan plan;
+    rc = plan_frame(ctx, cols, rows, plan);
+    if (rc) return rc;
+    FrameParams &fp = ctx->fp;
+    const bool tiled = plan.tiled, textured = plan.textured;
+    const size_t nbins = plan.nbins;
+    const unsigned cell_blocks = unsigned((plan.strip_cells + 255) / 256);
     const int set = int(ctx->frame % unsigned(kSets));  // buffer set of this frame (tiled path)
     const bool overlap = tiled && may_overlap && !ctx->ext_stream && ctx->overlap != 0;
     if (!overlap && ctx->overlapped_in_flight) {  // frames still running on the frame streams
@@ -336,17 +393,8 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
         if (rc) return rc;
     }
     if (tiled) {
-        // one triangle per k_setup lane and pass; more passes only beyond kMaxGroups workgroups
-        uint32_t chunk = (fp.n_tris + kMaxGroups - 1) / kMaxGroups;
-        chunk = (chunk + kSetupThreads - 1) / kSetupThreads * kSetupThreads;
-        fp.chunk = chunk;
-        fp.n_groups = (fp.n_tris + chunk - 1) / chunk;
         fp.frame = ctx->frame;
         fp.set = set;
-        fp.id_bits = 1;
-        while (fp.id_bits < kEntryMaskShift && (2ull * fp.n_tris - 1) >> fp.id_bits) fp.id_bits++;
-        fp.cls_bits = std::min(kEntryMaskShift - fp.id_bits, kMaxClassBits);
-        if (ctx->no_classes) fp.cls_bits = 0;
         const uint32_t want_cap = ctx->pool_cap_option ? ctx->pool_cap_option : 2u * fp.n_tris + 65536u;
         if (!ctx->d_entries[0] || ctx->pool_cap != want_cap) {
             rc = sync_streams(ctx);
@@ -356,7 +404,7 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
             for (int k = 0; k < kSets; k++) AR_HIP(ctx, hipMalloc(&ctx->d_entries[k], size_t(want_cap) * sizeof(uint32_t)));
             ctx->pool_cap = want_cap;
         }
-        const size_t want_groups = size_t(fp.n_groups) * 2 * chunk;
+        const size_t want_groups = size_t(fp.n_groups) * 2 * fp.chunk;
         if (!ctx->d_surv[0] || ctx->group_cap < want_groups) {
             rc = sync_streams(ctx);
             if (rc) return rc;
@@ -405,34 +453,33 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
         // Frames with few bins (small grids, strips of a frame) do without k_binscan: one launch and one gap between
         // dependent kernels less, which is most of what such a frame costs.  They need the totals behind the count
         // table at zero; a frame of the other kind (or a failed one) leaves them otherwise.
-        fp.fold_scan = (nbins <= size_t(kFoldScanBins) && !ctx->no_fold) ? 1 : 0;
         if (fp.fold_scan && !ctx->blocksum_zero[set])
             AR_HIP(ctx, hipMemsetAsync(blocksum, 0, 16 * size_t(kMaxBins) * sizeof(uint32_t), fs));
         ctx->blocksum_zero[set] = fp.fold_scan != 0;
         {
             Stamper s(ctx, K_SETUP, fs);
-            k_setup<<<fp.n_groups, kSetupThreads, nbins * sizeof(uint32_t), fs>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_box, ctx->d_surv[set], ctx->d_sid[set],
-                                                         ctx->d_surv_count[set], dircount, blocksum);
+            k_setup<false><<<fp.n_groups, kSetupThreads, nbins * sizeof(uint32_t), fs>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_box, ctx->d_surv[set], ctx->d_sid[set],
+                                                         ctx->d_surv_count[set], dircount, blocksum, nullptr, BatchStrides{});
         }
         if (!fp.fold_scan) {
             Stamper s(ctx, K_BINSCAN, fs);
-            k_binscan<<<dim3(unsigned((nbins + 63) / 64), 16), 64 * kScanWaves, 0, fs>>>(fp, dircount, blocksum);
+            k_binscan<false><<<dim3(unsigned((nbins + 63) / 64), 16), 64 * kScanWaves, 0, fs>>>(fp, dircount, blocksum, nullptr, BatchStrides{});
         }
         {
             Stamper s(ctx, K_FILL, fs);
-            k_fill<<<fp.n_groups, kSetupThreads, nbins * 2 * sizeof(uint32_t) + ((nbins + 3) & ~size_t(3)), fs>>>(fp, ctx->d_tri, ctx->d_surv[set], ctx->d_sid[set], ctx->d_surv_count[set], dircount, blocksum,
-                                                        ctx->d_state, ctx->d_entries[set], ctx->pool_cap, ctx->d_vis[set]);
+            k_fill<false><<<fp.n_groups, kSetupThreads, nbins * 2 * sizeof(uint32_t) + ((nbins + 3) & ~size_t(3)), fs>>>(fp, ctx->d_tri, ctx->d_surv[set], ctx->d_sid[set], ctx->d_surv_count[set], dircount, blocksum,
+                                                        ctx->d_state, ctx->d_entries[set], ctx->pool_cap, ctx->d_vis[set], nullptr, BatchStrides{});
         }
         {
             Stamper s(ctx, K_TILE, fs);
             const unsigned grid = unsigned((nbins + 7) / 8 * 8) << (2 * fp.bshift);
-            auto kernel = fp.tshift == 5 ? (textured ? k_tile<true, 5> : k_tile<false, 5>)
-                          : fp.tshift == 4 ? (textured ? k_tile<true, 4> : k_tile<false, 4>)
-                                           : (textured ? k_tile<true, 3> : k_tile<false, 3>);
+            auto kernel = fp.tshift == 5 ? (textured ? k_tile<true, 5, false> : k_tile<false, 5, false>)
+                          : fp.tshift == 4 ? (textured ? k_tile<true, 4, false> : k_tile<false, 4, false>)
+                                           : (textured ? k_tile<true, 3, false> : k_tile<false, 3, false>);
             kernel<<<grid, kTileThreads, 0, fs>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_triuv,
                                          ctx->d_atlas, ctx->d_tri, ctx->d_tri_t, ctx->d_entries[set], ctx->pool_cap, ctx->d_state, blocksum,
                                          ctx->d_vis[set], ctx->d_rgba[oset], ctx->d_depth[oset], ascii_out, ctx->d_ridx[set],
-                                         ctx->d_ids[oset]);
+                                         ctx->d_ids[oset], nullptr, BatchStrides{});
         }
         ctx->frame++;
     } else {
@@ -470,6 +517,178 @@ int enqueue_frame(ar_ctx *ctx, int cols, int rows, bool may_overlap) {
     ctx->last_oset = oset;
     ctx->last_stream = fs;
     ctx->last_slot = overlap ? set : kSets;
+    return 0;
+}
+
+void free_batch_set(BatchSet &b) {
+    (void)hipFree(b.d_surv); (void)hipFree(b.d_sid); (void)hipFree(b.d_surv_count); (void)hipFree(b.d_dircount); (void)hipFree(b.d_entries);
+    (void)hipFree(b.d_state); (void)hipFree(b.d_vis); (void)hipFree(b.d_ridx); (void)hipFree(b.d_rgba); (void)hipFree(b.d_ascii);
+    (void)hipFree(b.d_depth); (void)hipFree(b.d_ids); (void)hipFree(b.d_fps);
+    if (b.h_fps) (void)hipHostFree(b.h_fps);
+    if (b.ev_params) (void)hipEventDestroy(b.ev_params);
+    b = BatchSet();
+}
+
+// Makes batch set k hold n frames of the planned frame in ctx->fp (grows, never shrinks, while the grid stays the same).
+int ensure_batch_set(ar_ctx *ctx, int k, int n, int cols, int rows, const FramePlan &plan) {
+    BatchSet &b = ctx->batch[k];
+    const FrameParams &fp = ctx->fp;
+    const size_t cells = size_t(cols) * rows;
+    const size_t surv = size_t(fp.n_groups) * 2 * fp.chunk, table = size_t(fp.n_groups) * plan.nbins, dir = table + 16 * size_t(kMaxBins);
+    const size_t entries = ctx->pool_cap_option ? ctx->pool_cap_option : 2u * size_t(fp.n_tris) + 65536u;
+    if (b.frames >= n && b.cells == cells && b.surv >= surv && b.dir_table == table && b.entries == entries && (b.ids || !ctx->want_ids)) return 0;
+    int rc = sync_streams(ctx);
+    if (rc) return rc;
+    free_batch_set(b);
+    const size_t N = size_t(n);
+    AR_HIP(ctx, hipMalloc(&b.d_surv, N * surv * sizeof(uint2)));
+    AR_HIP(ctx, hipMalloc(&b.d_sid, N * surv * sizeof(uint32_t)));
+    AR_HIP(ctx, hipMalloc(&b.d_surv_count, N * (size_t(kMaxGroups) + 1) * sizeof(uint32_t)));
+    AR_HIP(ctx, hipMalloc(&b.d_dircount, N * dir * sizeof(uint32_t)));
+    AR_HIP(ctx, hipMalloc(&b.d_entries, N * entries * sizeof(uint32_t)));
+    AR_HIP(ctx, hipMalloc(&b.d_state, N * sizeof(BinState)));
+    AR_HIP(ctx, hipMalloc(&b.d_vis, N * cells * sizeof(uint64_t)));
+    AR_HIP(ctx, hipMalloc(&b.d_ridx, N * cells));
+    AR_HIP(ctx, hipMalloc(&b.d_rgba, N * cells * 4));
+    AR_HIP(ctx, hipMalloc(&b.d_ascii, N * cells));
+    AR_HIP(ctx, hipMalloc(&b.d_depth, N * cells * sizeof(float)));
+    if (ctx->want_ids) AR_HIP(ctx, hipMalloc(&b.d_ids, N * cells * sizeof(uint32_t)));
+    AR_HIP(ctx, hipMalloc(&b.d_fps, N * sizeof(FrameParams)));
+    AR_HIP(ctx, hipHostMalloc(&b.h_fps, N * sizeof(FrameParams), hipHostMallocDefault));
+    AR_HIP(ctx, hipEventCreateWithFlags(&b.ev_params, hipEventDisableTiming));
+    // defined contents for what the kernels do not write (rows outside a strip), idle values for what they expect to find idle
+    hipStream_t s = ctx->own_stream;
+    AR_HIP(ctx, hipMemsetAsync(b.d_state, 0, N * sizeof(BinState), s));
+    AR_HIP(ctx, hipMemsetAsync(b.d_dircount, 0, N * dir * sizeof(uint32_t), s));
+    AR_HIP(ctx, hipMemsetAsync(b.d_ridx, 0, N * cells, s));
+    AR_HIP(ctx, hipMemsetAsync(b.d_rgba, 0, N * cells * 4, s));
+    AR_HIP(ctx, hipMemsetAsync(b.d_ascii, 0, N * cells, s));
+    AR_HIP(ctx, hipMemsetAsync(b.d_depth, 0, N * cells * sizeof(float), s));
+    if (b.d_ids) AR_HIP(ctx, hipMemsetAsync(b.d_ids, 0xFF, N * cells * sizeof(uint32_t), s));
+    k_clear<<<2048, 256, 0, s>>>(b.d_vis, 0, N * cells);
+    AR_HIP(ctx, hipGetLastError());
+    AR_HIP(ctx, hipStreamSynchronize(s));
+    b.blocksum_zero = true;
+    b.frames = n; b.cells = cells; b.surv = surv; b.dircount = dir; b.dir_table = table; b.entries = entries; b.ids = ctx->want_ids;
+    return 0;
+}
+
+// n frames, cameras[f] = (proj, view) of frame f, in ONE chain of launches: every kernel of the tiled path runs once
+// for all frames (frame = blockIdx.z).  A frame that is bound by launch and hand-over latencies rather than by work - a
+// small scene, a strip of a frame on one of several GPUs - costs a fraction of a launch chain this way.  Frames that
+// cannot take that road (the direct path, textured frames) are rendered one by one into the same buffers.
+int enqueue_batch(ar_ctx *ctx, int cols, int rows, int n, const float *cameras, size_t ascii_stride) {
+    if (cols <= 0 || rows <= 0 || size_t(cols) * rows > (size_t(1) << 31)) return fail(ctx, AR_E_ARG, "ar_render_batch: bad grid %d x %d", cols, rows);
+    if (n <= 0 || n > kMaxBatchFrames || !cameras) return fail(ctx, AR_E_ARG, "ar_render_batch: 1..%d frames and their cameras expected (got %d)", kMaxBatchFrames, n);
+    const size_t cells = size_t(cols) * rows;
+    if (ctx->ascii_target && n > 1 && ascii_stride < size_t(cols))
+        return fail(ctx, AR_E_ARG, "ar_render_batch: with an ASCII target the frames' planes must lie at least a row apart (stride %zu)", ascii_stride);
+    if (ascii_target_misaligned(ctx, cols) || (ctx->ascii_target && (cols & 3) == 0 && (ascii_stride & 3u) != 0))
+        return fail(ctx, AR_E_ARG, "ar_render_batch: the ASCII target and its stride must be 4-byte aligned when the row length (%d) is a multiple of four", cols);
+    AR_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->n_tris == 0 || !ctx->d_vbo || !ctx->d_idx) return 0;  // raster.js:274: nothing to draw
+    float keep_proj[16], keep_view[16];
+    memcpy(keep_proj, ctx->proj, sizeof keep_proj);
+    memcpy(keep_view, ctx->view, sizeof keep_view);
+    auto restore = [&]() { memcpy(ctx->proj, keep_proj, sizeof keep_proj); memcpy(ctx->view, keep_view, sizeof keep_view); };
+    FramePlan plan;
+    int rc = plan_frame(ctx, cols, rows, plan);
+    if (rc) return rc;
+    const int k = int(ctx->batch_no % unsigned(kSets));
+    rc = ensure_batch_set(ctx, k, n, cols, rows, plan);
+    if (rc) return rc;
+    BatchSet &b = ctx->batch[k];
+    const bool overlap = plan.tiled && !plan.textured && !ctx->ext_stream && ctx->overlap != 0;
+    if (!overlap && ctx->overlapped_in_flight) {
+        rc = sync_streams(ctx);
+        if (rc) return rc;
+    }
+    hipStream_t fs = overlap ? ctx->fstream[k] : ctx->stream;
+    uint8_t *ascii_base = ctx->ascii_target ? ctx->ascii_target - ptrdiff_t(ctx->target_row) * cols : b.d_ascii;
+    const size_t ascii_step = ctx->ascii_target ? ascii_stride : cells;
+
+    if (!plan.tiled || plan.textured) {
+        // one by one through the single-frame path (its own buffers), each copied into the batch's planes behind it
+        uint8_t *keep_target = ctx->ascii_target;
+        for (int f = 0; f < n && !rc; f++) {
+            memcpy(ctx->proj, cameras + size_t(f) * 32, 16 * sizeof(float));
+            memcpy(ctx->view, cameras + size_t(f) * 32 + 16, 16 * sizeof(float));
+            if (keep_target) ctx->ascii_target = keep_target + size_t(f) * ascii_stride;
+            rc = enqueue_frame(ctx, cols, rows, false);
+            if (rc) break;
+            hipStream_t s = ctx->stream;
+            hipError_t e = hipMemcpyAsync(b.d_rgba + size_t(f) * cells * 4, ctx->d_rgba[0], cells * 4, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(b.d_depth + size_t(f) * cells, ctx->d_depth[0], cells * sizeof(float), hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess && !keep_target) e = hipMemcpyAsync(b.d_ascii + size_t(f) * cells, ctx->d_ascii[0], cells, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess && ctx->want_ids && b.d_ids && ctx->d_ids[0])
+                e = hipMemcpyAsync(b.d_ids + size_t(f) * cells, ctx->d_ids[0], cells * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) rc = fail(ctx, AR_E_HIP, "ar_render_batch: copy failed: %s", hipGetErrorString(e));
+        }
+        ctx->ascii_target = keep_target;
+        restore();
+        if (rc) return rc;
+        ctx->batch_no++;
+        ctx->last_batch = k; ctx->last_batch_frames = n; ctx->batch_cols = cols; ctx->batch_rows = rows;
+        ctx->last_stream = ctx->stream; ctx->last_slot = kSets;
+        return 0;
+    }
+
+    if (overlap) ctx->overlapped_in_flight = true;
+    // the frames' parameters: the planned frame with each frame's camera, staged in page-locked memory
+    if (b.params_pending) AR_HIP(ctx, hipEventSynchronize(b.ev_params));  // (the copy of the batch that used this set last: long done)
+    for (int f = 0; f < n; f++) {
+        memcpy(ctx->proj, cameras + size_t(f) * 32, 16 * sizeof(float));
+        memcpy(ctx->view, cameras + size_t(f) * 32 + 16, 16 * sizeof(float));
+        FramePlan again;
+        rc = plan_frame(ctx, cols, rows, again);
+        if (rc) { restore(); return rc; }
+        b.h_fps[f] = ctx->fp;
+        b.h_fps[f].set = f;       // index of the frame's binning state in the batch's array
+        b.h_fps[f].frame = uint32_t(f);
+    }
+    restore();
+    const FrameParams &fp = b.h_fps[0];
+    AR_HIP(ctx, hipMemcpyAsync(b.d_fps, b.h_fps, size_t(n) * sizeof(FrameParams), hipMemcpyHostToDevice, fs));
+    AR_HIP(ctx, hipEventRecord(b.ev_params, fs));
+    b.params_pending = true;
+    const size_t nbins = plan.nbins;
+    BatchStrides bs;
+    bs.surv = b.surv; bs.groups = size_t(kMaxGroups) + 1; bs.dircount = b.dircount; bs.entries = b.entries; bs.cells = cells; bs.ascii = ascii_step;
+    uint32_t *dircount = b.d_dircount, *blocksum = b.d_dircount + b.dir_table;
+    const unsigned N = unsigned(n);
+    // (frames without k_binscan want the totals behind the count table at zero: k_tile leaves them so, the allocation made them so)
+    if (fp.fold_scan && !b.blocksum_zero) AR_HIP(ctx, hipMemsetAsync(b.d_dircount, 0, size_t(b.frames) * b.dircount * sizeof(uint32_t), fs));
+    b.blocksum_zero = fp.fold_scan != 0;  // (frames without k_binscan put the totals back to zero, the others leave k_binscan's there)
+    {
+        Stamper s(ctx, K_SETUP, fs);
+        k_setup<true><<<dim3(fp.n_groups, 1, N), kSetupThreads, nbins * sizeof(uint32_t), fs>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_box, b.d_surv, b.d_sid,
+                                                                                              b.d_surv_count, dircount, blocksum, b.d_fps, bs);
+    }
+    if (!fp.fold_scan) {
+        Stamper s(ctx, K_BINSCAN, fs);
+        k_binscan<true><<<dim3(unsigned((nbins + 63) / 64), 16, N), 64 * kScanWaves, 0, fs>>>(fp, dircount, blocksum, b.d_fps, bs);
+    }
+    {
+        Stamper s(ctx, K_FILL, fs);
+        k_fill<true><<<dim3(fp.n_groups, 1, N), kSetupThreads, nbins * 2 * sizeof(uint32_t) + ((nbins + 3) & ~size_t(3)), fs>>>(
+            fp, ctx->d_tri, b.d_surv, b.d_sid, b.d_surv_count, dircount, blocksum, b.d_state, b.d_entries, uint32_t(b.entries), b.d_vis, b.d_fps, bs);
+    }
+    {
+        Stamper s(ctx, K_TILE, fs);
+        const unsigned grid = unsigned((nbins + 7) / 8 * 8) << (2 * fp.bshift);
+        auto kernel = fp.tshift == 5 ? k_tile<false, 5, true> : fp.tshift == 4 ? k_tile<false, 4, true> : k_tile<false, 3, true>;
+        kernel<<<dim3(grid, 1, N), kTileThreads, 0, fs>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_triuv, ctx->d_atlas, ctx->d_tri, ctx->d_tri_t,
+                                                         b.d_entries, uint32_t(b.entries), b.d_state, blocksum, b.d_vis, b.d_rgba, b.d_depth, ascii_base,
+                                                         b.d_ridx, b.d_ids, b.d_fps, bs);
+    }
+    if (fp.mode_on == 1) {
+        Stamper s(ctx, K_ASCII, fs);
+        launch_ascii_planes(fp, b.d_ridx, ascii_base, fs, n, b.d_fps, bs);
+    }
+    AR_HIP(ctx, hipGetLastError());
+    ctx->batch_no++;
+    ctx->last_batch = k; ctx->last_batch_frames = n; ctx->batch_cols = cols; ctx->batch_rows = rows;
+    ctx->last_stream = fs; ctx->last_slot = overlap ? k : kSets;
     return 0;
 }
 

@@ -5,6 +5,8 @@
 // rows works with any number of devices).  Every device holds the whole mesh and renders its strip with the ordinary
 // per-context calls (ar_set_strip, ar_set_ascii_target, ar_render_async), each from a host thread of its own - five kernel
 // launches per frame and device are more than one thread can issue for eight devices at the rate the GPUs render.
+// A member hands the frames posted to it to its GPU up to sixteen at a time, as one chain of kernel launches
+// (ar_render_batch_async): a strip of a frame is bound by launches and hand-overs, not by work.
 // A strip lands in a slot of a ring (slots as tall as the tallest strip); every `batch` frames ONE all-gather per device
 // combines the rings, so that afterwards every device holds every strip of those frames.  There are two rings: while one is
 // gathered the next frames fill the other; a frame waits (on the GPU) only for the gather that last used its ring, the gather
@@ -88,8 +90,12 @@ struct ar_group {
         char err[256] = "";
         // the ring bookkeeping, identical in every member (each advances it by the same commands)
         int cur = 0, filled = 0, last = -1, gathered = 0;
+        // frames posted but not yet enqueued on the GPU: they go out together, as one chain of launches (ar_render_batch_async)
+        std::vector<float> pending;  // 32 floats (projection, view) per frame
+        int pending_cols = 0, pending_rows = 0;
     };
     int n = 0, batch = 1;
+    int chain = 16;                // frames a member hands to its GPU per call (one chain of launches): at most this many
     int cols = 0, rows = 0;        // grid the rings are sized for (0: none yet)
     size_t slot_bytes = 0;         // one strip slot: tallest strip x cols
     std::vector<Member *> members;
@@ -128,20 +134,32 @@ void member_gather(ar_group::Member *m) {
     m->cur = (m->cur + 1) % kGroupRings;
 }
 
-void member_frame(ar_group::Member *m, const GroupCommand &c) {
+// Enqueues the frames posted so far: one batch call, their strips into consecutive slots of the ring being filled.
+void member_issue(ar_group::Member *m) {
     ar_group *g = m->group;
+    const int n = int(m->pending.size() / 32);
+    if (n == 0) return;
     int row0 = 0, row1 = 0;
-    ar_strip_rows(c.rows, g->n, m->index, &row0, &row1);
+    ar_strip_rows(m->pending_rows, g->n, m->index, &row0, &row1);
     if (row1 > row0) {  // (more devices than rows leave some without a strip: they only take part in the gathers)
         uint8_t *slot = m->send[m->cur] + size_t(m->filled) * g->slot_bytes;
         int rc = ar_set_strip(m->ctx, row0, row1);
         if (!rc) rc = ar_set_ascii_target(m->ctx, slot, row0);
-        if (!rc) rc = ar_set_camera(m->ctx, c.proj, c.view);
-        if (!rc) rc = ar_render_async(m->ctx, c.cols, c.rows);
-        if (rc) { member_fail(m, rc, "frame", ar_last_error(m->ctx)); return; }
+        if (!rc) rc = ar_render_batch_async(m->ctx, m->pending_cols, m->pending_rows, n, m->pending.data(), g->slot_bytes);
+        if (rc) member_fail(m, rc, "frames", ar_last_error(m->ctx));
     }
-    m->filled++;
+    m->pending.clear();
+    m->filled += n;
     if (m->filled == g->batch) member_gather(m);
+}
+
+void member_frame(ar_group::Member *m, const GroupCommand &c) {
+    ar_group *g = m->group;
+    m->pending_cols = c.cols; m->pending_rows = c.rows;
+    m->pending.insert(m->pending.end(), c.proj, c.proj + 16);
+    m->pending.insert(m->pending.end(), c.view, c.view + 16);
+    const int n = int(m->pending.size() / 32);
+    if (m->filled + n == g->batch || n == g->chain) member_issue(m);  // the ring is full, or a chain's worth has come together
 }
 
 void member_loop(ar_group::Member *m) {
@@ -159,7 +177,7 @@ void member_loop(ar_group::Member *m) {
         }
         if (c.kind == GroupCommand::STOP) return;
         if (m->rc) continue;  // after a failure the rest of the queue is dropped
-        if (c.kind == GroupCommand::FLUSH) member_gather(m);
+        if (c.kind == GroupCommand::FLUSH) { member_issue(m); member_gather(m); }
         else member_frame(m, c);
     }
 }
@@ -228,6 +246,7 @@ ar_group *ar_group_create(int n, const int *device_ids, int batch) {
     if (!g) { group_fail(nullptr, AR_E_NOMEM, "out of host memory"); return nullptr; }
     g->n = n;
     g->batch = batch;
+    g->chain = batch < 16 ? batch : 16;
     bool ok = true;
     for (int i = 0; i < n && ok; i++) {
         auto *m = new (std::nothrow) ar_group::Member();
@@ -293,8 +312,8 @@ int ar_group_render_async(ar_group *g, int cols, int rows, const float proj[16],
     if (cols <= 0 || rows <= 0 || !proj || !view || size_t(cols) * size_t(rows) > (size_t(1) << 31))
         return group_fail(g, AR_E_ARG, "ar_group_render_async: bad arguments (%d x %d)", cols, rows);
     if (cols != g->cols || rows != g->rows) {
-        // a new grid: drain, then rings for its strips (slots as tall as the tallest strip)
-        int rc = group_quiesce(g);
+        // a new grid: finish what was posted for the old one, then rings for the new strips (slots as tall as the tallest strip)
+        int rc = g->cols ? ar_group_sync(g) : group_quiesce(g);
         if (rc) return rc;
         group_free_rings(g);
         const size_t tallest = size_t((rows + g->n - 1) / g->n);

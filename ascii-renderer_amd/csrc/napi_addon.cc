@@ -781,6 +781,46 @@ napi_value js_set_id_output(napi_env env, napi_callback_info info) {
     return nullptr;
 }
 
+// renderBatchAsync(handle, cols, rows, Float32Array cameras (32 floats per frame: projection, view), asciiStride): ar_render_batch_async
+napi_value js_render_batch_async(napi_env env, napi_callback_info info) {
+    napi_value argv[5];
+    if (!get_args(env, info, 5, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    void *cams;
+    size_t n;
+    if (!get_typed(env, argv[3], napi_float32_array, &cams, &n, false)) return nullptr;
+    if (n == 0 || n % 32) { napi_throw_range_error(env, nullptr, "renderBatchAsync: 32 floats (projection, view) per frame expected"); return nullptr; }
+    double stride = 0;
+    napi_get_value_double(env, argv[4], &stride);
+    if (!(stride >= 0)) stride = 0;
+    if (ar_render_batch_async(ctx, get_i32(env, argv[1]), get_i32(env, argv[2]), int(n / 32), static_cast<const float *>(cams), size_t(stride)))
+        return throw_ar(env, ctx, "ar_render_batch_async");
+    return nullptr;
+}
+
+// readBatch(handle, cols, rows, frame, rgba|null, depth|null, ascii|null, ids|null): ar_read_batch
+napi_value js_read_batch(napi_env env, napi_callback_info info) {
+    napi_value argv[8];
+    if (!get_args(env, info, 8, argv)) return nullptr;
+    ar_ctx *ctx = get_ctx(env, argv[0]);
+    if (!ctx) return nullptr;
+    const int cols = get_i32(env, argv[1]), rows = get_i32(env, argv[2]);
+    void *rgba, *depth, *ascii, *ids;
+    size_t nr, nd, na, ni;
+    if (!get_typed(env, argv[4], napi_uint8_array, &rgba, &nr, true) || !get_typed(env, argv[5], napi_float32_array, &depth, &nd, true) ||
+        !get_typed(env, argv[6], napi_uint8_array, &ascii, &na, true) || !get_typed(env, argv[7], napi_uint32_array, &ids, &ni, true))
+        return nullptr;
+    const size_t n = size_t(cols > 0 ? cols : 0) * size_t(rows > 0 ? rows : 0);
+    if ((rgba && nr != n * 4) || (depth && nd != n) || (ascii && na != n) || (ids && ni != n)) {
+        napi_throw_range_error(env, nullptr, "readBatch: output array size does not match cols*rows");
+        return nullptr;
+    }
+    if (ar_read_batch(ctx, get_i32(env, argv[3]), static_cast<uint8_t *>(rgba), static_cast<float *>(depth), static_cast<uint8_t *>(ascii), static_cast<uint32_t *>(ids)))
+        return throw_ar(env, ctx, "ar_read_batch");
+    return nullptr;
+}
+
 // updatePositions(handle, Float32Array data, floatsPerVertex (3 | 9), flags): ar_update_positions
 napi_value js_update_positions(napi_env env, napi_callback_info info) {
     napi_value argv[4];
@@ -942,6 +982,8 @@ napi_value init(napi_env env, napi_value exports) {
         {"allocHost", nullptr, js_alloc_host, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"quantizeColors", nullptr, js_quantize_colors, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"present", nullptr, js_present, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"renderBatchAsync", nullptr, js_render_batch_async, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
+        {"readBatch", nullptr, js_read_batch, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"updatePositions", nullptr, js_update_positions, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"stripRows", nullptr, js_strip_rows, nullptr, nullptr, nullptr, napi_enumerable, nullptr},
         {"groupCreate", nullptr, js_group_create, nullptr, nullptr, nullptr, napi_enumerable, nullptr},

@@ -37,6 +37,7 @@ struct FrameParams {
     int tshift;      // log2 of the tile height in rows (5, 4 or 3)
     int id_bits;     // bits of a bin entry that hold 2*slot + sub (enough for the mesh) ...
     int cls_bits;    // ... and, above them, so many bits of work class (0..6; what is left below the tile mask)
+    int cls_area;    // 1: the class's second key is the triangle's area in cells (k_setup's estimate), 0: the width of its cell range
     int fold_scan;   // 1: no k_binscan in this frame - k_setup adds up the totals per bin and row block, k_fill sums the
                      // table rows before its own (frames with few bins, where that is cheaper than a kernel)
     uint32_t chunk, n_groups;  // triangles per k_setup workgroup, number of those workgroups
@@ -44,6 +45,17 @@ struct FrameParams {
     int set;         // buffer set of this frame (frame % kSets): binning state block, survivor slots, ...
     int tex_w, tex_h;  // atlas size in texels; 0 x 0 while texturing is off
     uint8_t ramp[AR_MAX_RAMP];
+};
+
+// Several frames in one launch chain (ar_render_batch_async): the kernels of the tiled path take the frame from blockIdx.z,
+// its parameters from an array in device memory and every per-frame buffer at a frame's stride from the first frame's.
+struct BatchStrides {
+    size_t surv;      // survivor places (cell-range tuples, ids) per frame
+    size_t groups;    // survivor counters per frame
+    size_t dircount;  // words of count table + row-block totals per frame
+    size_t entries;   // bin entries per frame
+    size_t cells;     // cells per frame: visibility keys, ramp-index plane, RGBA (x 4 bytes), depth, ids
+    size_t ascii;     // bytes from one frame's ASCII plane to the next (the context's planes, or the caller's target)
 };
 
 // Setup record of one (sub-)triangle: edge functions, per-vertex w and clip z, cell range, key id.
@@ -202,13 +214,13 @@ __device__ __forceinline__ void edges_from_screen(const S &s, Edges &e) {
 
 // det = v0 . (v1 x v2) > 0: counter-clockwise in the window, i.e. front facing; <= 0 is culled
 // (back face or zero area).
-__device__ __forceinline__ bool front_facing(const Screen &s) {
+__device__ __forceinline__ double facing_det(const Screen &s) {
     const double a0 = diff_of_products(s.Y[1], s.W[2], s.Y[2], s.W[1]);
     const double b0 = diff_of_products(s.X[2], s.W[1], s.X[1], s.W[2]);
     const double c0 = diff_of_products(s.X[1], s.Y[2], s.X[2], s.Y[1]);
-    const double det = (double(s.X[0]) * a0 + double(s.Y[0]) * b0) + double(s.W[0]) * c0;
-    return det > 0.0;
+    return (double(s.X[0]) * a0 + double(s.Y[0]) * b0) + double(s.W[0]) * c0;
 }
+__device__ __forceinline__ bool front_facing(const Screen &s) { return facing_det(s) > 0.0; }
 
 // Inclusive cell range (GL window coordinates) that contains every covered cell centre, clamped to
 // the viewport columns and to window rows [jlo, jhi].  False when empty.  The range only has to be a

@@ -409,6 +409,7 @@ __device__ __forceinline__ void bin_range(const FrameParams &fp, int i0, int i1,
 struct Candidate {
     Screen sc;
     int i0, i1, j0, j1;
+    uint32_t area_cls;  // 0..15: window area in cells on a logarithmic scale, two steps per octave of 2 * area + 1 - a hint for the order of work
 };
 
 // Setup of the triangle with vertex positions p[0..8]: transform, near clip, cull, cell range within
@@ -426,8 +427,15 @@ __device__ __forceinline__ void triangle_setup(const FrameParams &fp, const floa
     for (int s = 0; s < 2; s++) {
         if (s >= ns) continue;
         const Vert<0> t0 = s ? s1[0] : s0[0], t1 = s ? s1[1] : s0[1], t2 = s ? s1[2] : s0[2];
-        if (!to_screen(t0.c, t1.c, t2.c, fp.hw, fp.hh, c[s].sc) || !front_facing(c[s].sc)) continue;
+        if (!to_screen(t0.c, t1.c, t2.c, fp.hw, fp.hh, c[s].sc)) continue;
+        const double det = facing_det(c[s].sc);
+        if (!(det > 0.0)) continue;
         have[s] = cell_range(c[s].sc.X, c[s].sc.Y, c[s].sc.W, fp.cols, jlo, jhi, c[s].i0, c[s].i1, c[s].j0, c[s].j1);
+        // det = 2 * area * w0 w1 w2: twice the area in cells, as an integer, binned by its bit length (any value will do:
+        // it orders work, it decides nothing)
+        const float twice = float(det) * __builtin_amdgcn_rcpf((c[s].sc.W[0] * c[s].sc.W[1]) * c[s].sc.W[2]);
+        const float v = fminf(fmaxf(twice, 0.0f), 250.0f) + 1.0f;  // in [1, 251]: exponent 0..7, two steps per octave from the top mantissa bit
+        c[s].area_cls = (__float_as_uint(v) >> 22) - (127u << 1);
     }
 }
 
@@ -476,10 +484,18 @@ __device__ __forceinline__ bool sub_triangle_screen(const FrameParams &fp, const
 // meets the survivors.  surv: the cell range of a survivor, (i0 | i1 << 16, j0 | j1 << 16); sid: 2*slot + sub -
 // all k_fill needs.  Nothing else of the setup is kept: the tiles redo it from the triangle records.
 // One triangle per lane and pass; chunk (a multiple of the workgroup size) bounds the passes of a workgroup.
-__global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const float *__restrict__ tripos, size_t stride,
+// BATCH: one launch for several frames (frame = blockIdx.z, parameters from fps, buffers at the frame's stride).
+template <bool BATCH>
+__global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp_one, const float *__restrict__ tripos, size_t stride,
                                                          const float *__restrict__ box, uint2 *__restrict__ surv,
                                                          uint32_t *__restrict__ sid, uint32_t *__restrict__ surv_count,
-                                                         uint32_t *__restrict__ dircount, uint32_t *__restrict__ blocksum) {
+                                                         uint32_t *__restrict__ dircount, uint32_t *__restrict__ blocksum,
+                                                         const FrameParams *__restrict__ fps, BatchStrides bs) {
+    const FrameParams &fp = BATCH ? fps[blockIdx.z] : fp_one;
+    if (BATCH) {
+        const size_t f = blockIdx.z;
+        surv += f * bs.surv; sid += f * bs.surv; surv_count += f * bs.groups; dircount += f * bs.dircount; blocksum += f * bs.dircount;
+    }
     // (LDS sized by the launch to the frame's bins, not to the most a frame can have: the frame's kernels run beside
     // the tile resolve of the frame before, which leaves them a fifth of a compute unit's LDS)
     extern __shared__ uint32_t bins_lds[];
@@ -549,7 +565,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const f
             if (!have[s]) continue;
             const uint32_t loc = loc_base + slot;
             slot++;
-            sid[loc] = 2u * t + uint32_t(s);
+            sid[loc] = (2u * t + uint32_t(s)) | (c[s].area_cls << kEntryMaskShift);  // (ids stay below 2^28: the hint rides above them)
             surv[loc] = make_uint2(uint32_t(c[s].i0) | (uint32_t(c[s].i1) << 16), uint32_t(c[s].j0) | (uint32_t(c[s].j1) << 16));
             int bx0, bx1, by0, by1;
             bin_range(fp, c[s].i0, c[s].i1, c[s].j0, c[s].j1, bx0, bx1, by0, by1);
@@ -582,7 +598,11 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp, const f
 constexpr int kScanWaves = 4;
 constexpr int kFoldScanBins = 160;  // frames with at most so many bins go without k_binscan (FrameParams::fold_scan)
 static_assert(kMaxGroups <= 16u * 16u * kScanWaves, "a wavefront of k_binscan takes at most 16 rows of its row block");
-__global__ __launch_bounds__(64 * kScanWaves) void k_binscan(FrameParams fp, uint32_t *__restrict__ table, uint32_t *__restrict__ blocksum) {
+template <bool BATCH>
+__global__ __launch_bounds__(64 * kScanWaves) void k_binscan(FrameParams fp_one, uint32_t *__restrict__ table, uint32_t *__restrict__ blocksum,
+                                                              const FrameParams *__restrict__ fps, BatchStrides bs) {
+    const FrameParams &fp = BATCH ? fps[blockIdx.z] : fp_one;
+    if (BATCH) { table += size_t(blockIdx.z) * bs.dircount; blocksum += size_t(blockIdx.z) * bs.dircount; }
     __shared__ uint32_t part[kScanWaves][64];
     const int nbins = fp.nbx * fp.nby;
     const int lane = int(threadIdx.x & 63u), w = int(threadIdx.x >> 6);
@@ -621,13 +641,20 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_binscan(FrameParams fp, uin
 // start of the bin + entries of earlier row blocks + entries of earlier workgroups of its own row block (the
 // scanned table).  The totals are 16 x bins words read from L2 per workgroup; recomputing them here saves the frame
 // a kernel whose only job was this scan.  Workgroup 0 also publishes start / total / overflow for k_tile.
-__global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const TriStatic *__restrict__ tri,
+template <bool BATCH>
+__global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp_one, const TriStatic *__restrict__ tri,
                                                         const uint2 *__restrict__ surv, const uint32_t *__restrict__ sid,
                                                         const uint32_t *__restrict__ surv_count,
                                                         const uint32_t *__restrict__ dircount,
                                                         const uint32_t *__restrict__ blocksum, BinState *__restrict__ state,
                                                         uint32_t *__restrict__ entries, uint32_t entries_cap,
-                                                        uint64_t *__restrict__ vis) {
+                                                        uint64_t *__restrict__ vis, const FrameParams *__restrict__ fps, BatchStrides bs) {
+    const FrameParams &fp = BATCH ? fps[blockIdx.z] : fp_one;
+    if (BATCH) {
+        const size_t f = blockIdx.z;
+        surv += f * bs.surv; sid += f * bs.surv; surv_count += f * bs.groups; dircount += f * bs.dircount; blocksum += f * bs.dircount;
+        entries += f * bs.entries; vis += f * bs.cells;
+    }
     extern __shared__ uint32_t bins_lds[];  // (sized by the launch to the frame's bins, as in k_setup)
     const uint32_t tid = threadIdx.x;
     const int nbins = fp.nbx * fp.nby;
@@ -693,7 +720,8 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Tr
     for (uint32_t s = tid; s < n; s += kSetupThreads) {
         const uint32_t loc = loc_base + s;
         const uint2 sv = surv[loc];
-        const uint32_t id = sid[loc];  // 2*slot + sub: what the entries carry
+        const uint32_t id = sid[loc] & kEntryLocMask;  // 2*slot + sub: what the entries carry
+        const int area_cls = int(sid[loc] >> kEntryMaskShift);
         const int i0 = int(sv.x & 0xFFFFu), i1 = int(sv.x >> 16), j0 = int(sv.y & 0xFFFFu), j1 = int(sv.y >> 16);
         const int r0 = fp.rows - 1 - j1 - fp.ya, r1 = fp.rows - 1 - j0 - fp.ya;  // rows relative to the strip
         const int tx0 = i0 >> 6, tx1 = i1 >> 6, ty0 = r0 >> fp.tshift, ty1 = r1 >> fp.tshift;
@@ -704,7 +732,14 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp, const Tr
         // lane: k_tile orders every tile's list by this class so that a wavefront's triangles are of one kind.  The
         // class steers the order of the work only, never a result.
         const int hb = min(fp.cls_bits, 3), wb = fp.cls_bits - hb;
-        const uint32_t cls = uint32_t(((min(j1 - j0 + 1, 1 << hb) - 1) << wb) | (min(i1 - i0 + 1, 1 << wb) - 1)) << fp.id_bits;
+        uint32_t cls;
+        if (fp.cls_area == 2) {        // area first (as many of its four bits as fit), rows in what is left
+            const int ab = min(fp.cls_bits, 4), rb = fp.cls_bits - ab;
+            cls = uint32_t(((area_cls >> (4 - ab)) << rb) | (min(j1 - j0 + 1, 1 << rb) - 1)) << fp.id_bits;
+        } else {
+            const int second = fp.cls_area ? (area_cls >> (4 - wb)) : (min(i1 - i0 + 1, 1 << wb) - 1);
+            cls = uint32_t(((min(j1 - j0 + 1, 1 << hb) - 1) << wb) | second) << fp.id_bits;
+        }
         bool direct = false;
         for (int by = by0; by <= by1; by++)
             for (int bx = bx0; bx <= bx1; bx++) {

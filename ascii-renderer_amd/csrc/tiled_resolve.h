@@ -281,8 +281,9 @@ __device__ __forceinline__ void raster_small(const FrameParams &fp, Screen sc, u
 __device__ __forceinline__ uint32_t list_slot(uint32_t p) { return p ^ ((0u - ((p >> 8) & 1u)) & 255u); }
 
 // TEX: the frame samples an atlas (texel coordinates and atlas are only read then).  SH: log2 of the tile height.
-template <bool TEX, int SH>
-__global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const float *__restrict__ vbo,
+// BATCH: one launch for several frames (frame = blockIdx.z, parameters from fps, per-frame buffers at the frame's stride).
+template <bool TEX, int SH, bool BATCH>
+__global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp_one, const float *__restrict__ vbo,
                                               const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
                                               const uint4 *__restrict__ triuv, const uint32_t *__restrict__ atlas,
                                               const TriStatic *__restrict__ tri, const TriStatic *__restrict__ tri_t,
@@ -291,8 +292,15 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const flo
                                               uint64_t *__restrict__ vis,
                                               uint8_t *__restrict__ rgba, float *__restrict__ depth,
                                               uint8_t *__restrict__ ascii, uint8_t *__restrict__ ridx,
-                                              uint32_t *__restrict__ ids) {
+                                              uint32_t *__restrict__ ids, const FrameParams *__restrict__ fps, BatchStrides bs) {
     constexpr int kTileH = 1 << SH, kTileCells = kTileW * kTileH;
+    const FrameParams &fp = BATCH ? fps[blockIdx.z] : fp_one;
+    if (BATCH) {
+        const size_t f = blockIdx.z;
+        entries += f * bs.entries; blocksum += f * bs.dircount; vis += f * bs.cells; rgba += f * bs.cells * 4; depth += f * bs.cells;
+        ascii += f * bs.ascii; ridx += f * bs.cells;
+        if (ids) ids += f * bs.cells;
+    }
     __shared__ uint64_t keys[kTileCells];
     __shared__ uint32_t list[kTileListMax];
     __shared__ uint32_t big[kTileBigMax];
@@ -505,7 +513,8 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp, const flo
         const uint32_t id = low >> 1;
         const TriStatic ts = tri_t[id >> 1];  // (the winner is known by its own index: the copy kept in that order)
         uint8_t px[4];
-        shade_from_triangle<TEX>(fp, *kernarg_params(), vbo, idx, triattr, triuv, atlas, ts, id, (low & 1u) != 0u, i, fp.rows - 1 - rr, px);
+        if constexpr (BATCH) shade_from_triangle<TEX>(fp, fp, vbo, idx, triattr, triuv, atlas, ts, id, (low & 1u) != 0u, i, fp.rows - 1 - rr, px);
+        else shade_from_triangle<TEX>(fp, *kernarg_params(), vbo, idx, triattr, triuv, atlas, ts, id, (low & 1u) != 0u, i, fp.rows - 1 - rr, px);
         if (fp.want_ids) ids[size_t(rr) * fp.cols + i] = id;
         // untextured frames have alpha 255 everywhere: the byte carries the cell's ramp index to the output step
         // instead, which then has no arithmetic left to do per cell

@@ -531,6 +531,33 @@ export class HipRasterBackend {
     return true;
   }
 
+  // Several frames that differ in their camera only, handed over at once (ar_render_batch_async): the frames share one
+  // chain of kernel launches, which is most of what a small scene's frame costs.  cameras: [{pos: {x, y, z} | [x, y, z],
+  // yaw, pitch}, ...] - the values the live camera would have had at each of the frames.  Returns the number of frames
+  // enqueued (0 when there is nothing to draw); readBatch(frame, planes) then copies frame `frame` out (it waits).
+  renderBatch(cameras, appState) {
+    this._ensure();
+    const w = ((appState && appState.cols) | 0) || (config.VIRTUAL_GRID_WIDTH | 0) || 1;
+    const h = ((appState && appState.rows) | 0) || (config.VIRTUAL_GRID_HEIGHT | 0) || 1;
+    this._width = w; this._height = h;
+    if (!this._hasGeometry || !cameras || !cameras.length) return 0;
+    this._uploadFrameState(w, h, appState);
+    const packed = new Float32Array(32 * cameras.length);
+    cameras.forEach((c, k) => {
+      const p = Array.isArray(c.pos) ? { x: c.pos[0], y: c.pos[1], z: c.pos[2] } : c.pos;
+      const m = cameraMatrices({ pos: p, yaw: c.yaw, pitch: c.pitch }, w, h);
+      packed.set(m.proj, 32 * k); packed.set(m.view, 32 * k + 16);
+    });
+    native().renderBatchAsync(this._h, w, h, packed, 0);
+    return cameras.length;
+  }
+
+  // Planes of frame `frame` of the last renderBatch: {rgba, depth, ascii, ids} typed arrays to fill, any may be absent.
+  readBatch(frame, planes) {
+    const p = planes || {};
+    native().readBatch(this._h, this._width, this._height, frame | 0, p.rgba || null, p.depth || null, p.ascii || null, p.ids || null);
+  }
+
   // True when collect(token) would not wait.
   ready(token) { return !token || native().poll(this._h, token.ticket); }
 

@@ -59,6 +59,9 @@ def parse_args(argv=None):
     ap.add_argument("--gather-batch", type=int, default=16, help="frames per RCCL all-gather (multi-GPU runs)")
     ap.add_argument("--force-gather", action="store_true",
                     help="take the strip + all-gather path even with one rank (rehearsal of the multi-GPU loop on one GPU)")
+    ap.add_argument("--frames-per-chain", type=int, default=16,
+                    help="frames handed to the library per call (ar_render_batch_async: one chain of kernel launches for all of "
+                         "them, a camera each); 1 = one call and one chain per frame (ar_render_async)")
     ap.add_argument("--native-gather", action="store_true",
                     help="one process for all --gpus devices: the library's own group (a host thread and a context per device, "
                          "RCCL all-gathers inside the library) instead of one torch.distributed rank per GPU")
@@ -197,6 +200,11 @@ def main(argv=None):
         cam = dict(sc["camera"])
         cam["yaw"] = cam["yaw"] + YAW_JITTER * math.sin(2.0 * math.pi * k / N_CAMERAS)
         cams.append(R.prepare_camera(*host.camera_matrices(cam, args.cols, args.rows, 1.0)))
+    # the same cameras as one array (twice over, so that any run of up to N_CAMERAS consecutive frames is a slice of it)
+    cam_rows = R.pack_cameras([host.camera_matrices(dict(sc["camera"], yaw=sc["camera"]["yaw"] + YAW_JITTER * math.sin(2.0 * math.pi * k / N_CAMERAS)),
+                                                    args.cols, args.rows, 1.0) for k in range(N_CAMERAS)])
+    cam_rows = np.ascontiguousarray(np.concatenate([cam_rows, cam_rows], axis=0))
+    chain = max(1, min(args.frames_per_chain, N_CAMERAS))
     frame_no = [0]
     row0, row1 = mg.strip_bounds(args.rows, n_strips, rank)
     ts = None
@@ -233,6 +241,26 @@ def main(argv=None):
             R.render_async(args.cols, args.rows)
             b.advance()
 
+    def frames(n, b=None, per_chain=1):
+        """n frames, a new camera each: one launch chain per frame, or per_chain frames per chain (the group batches by itself)."""
+        if per_chain <= 1 or (b is G and G is not None):
+            for _ in range(n):
+                step(b)
+            return
+        left = n
+        while left > 0:
+            m = min(per_chain, left)
+            if b is not None:
+                m = min(m, b.batch - b.filled)                      # a chain's strips fill consecutive slots of one ring
+                R.set_ascii_target(b.slot_ptr(), row0)
+            start = frame_no[0] % N_CAMERAS
+            R.render_batch_async(args.cols, args.rows, cam_rows[start:start + m], ascii_stride=(b.h * b.cols if b is not None else 0))
+            frame_no[0] += m
+            left -= m
+            if b is not None:
+                for _ in range(m):
+                    b.advance()
+
     def fence(b=None):
         if b is G and G is not None:
             G.sync()
@@ -245,11 +273,10 @@ def main(argv=None):
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed_round(n, b=None):
+    def timed_round(n, b=None, per_chain=1):
         """n frames between two fences; seconds, the maximum over the ranks."""
         t0 = time.perf_counter()
-        for _ in range(n):
-            step(b)
+        frames(n, b, per_chain)
         fence(b)
         dt = time.perf_counter() - t0
         if world > 1:
@@ -258,29 +285,33 @@ def main(argv=None):
             dt = float(t.item())
         return dt
 
-    def measure(n, b=None):
+    def measure(n, b=None, per_chain=1):
         """Rounds until MIN_TIMED_S has been measured; (median seconds per frame, rounds, frames per round).
         A round of n frames that lasts under MIN_ROUND_S is mostly pipeline fill and drain (a frame's latency is
         about two frame times), so short rounds are run as a whole number of n-frame blocks back to back; the
         counts follow from the first block's all-rank maximum, so every rank runs the same."""
-        first = timed_round(n, b)
+        first = timed_round(n, b, per_chain)
         blocks = max(1, int(math.ceil(MIN_ROUND_S / max(first, 1e-9))))
         per_round = n * blocks
-        one = first if blocks == 1 else timed_round(per_round, b)
+        one = first if blocks == 1 else timed_round(per_round, b, per_chain)
         rounds = min(MAX_ROUNDS, max(1, int(math.ceil(MIN_TIMED_S / max(one, 1e-9)))))
-        dts = sorted([one] + [timed_round(per_round, b) for _ in range(rounds - 1)])
+        dts = sorted([one] + [timed_round(per_round, b, per_chain) for _ in range(rounds - 1)])
         med = dts[len(dts) // 2] if len(dts) % 2 else 0.5 * (dts[len(dts) // 2 - 1] + dts[len(dts) // 2])
         return med / per_round, len(dts), per_round
 
     if native:
         batcher = G
-    for _ in range(args.warmup):
-        step(batcher)
+    frames(args.warmup, batcher, chain)
     fence(batcher)
-    frame_s, rounds, frames_per_round = measure(args.steps, batcher)
+    frame_s, rounds, frames_per_round = measure(args.steps, batcher, chain)
     fps = 1.0 / frame_s
 
     extras = {}
+    if chain > 1 and not args.no_extras:
+        # the same frames with one call and one chain of launches per frame (what the line reported before frames could share a chain)
+        frames(args.warmup, batcher, 1)
+        fence(batcher)
+        extras["fps_one_chain_per_frame"] = 1.0 / measure(args.steps, batcher, 1)[0]
     gather_ok = None
     if native:
         # the gathered grid of the last frame, as every device holds it, must be the full frame
@@ -308,10 +339,9 @@ def main(argv=None):
         if not args.no_extras and args.gather_batch != 1:
             # the same loop with one all-gather per frame
             b1 = make_batcher(1)
-            for _ in range(args.warmup):
-                step(b1)
+            frames(args.warmup, b1, 1)
             fence(b1)
-            extras["fps_gather_every_frame"] = 1.0 / measure(args.steps, b1)[0]
+            extras["fps_gather_every_frame"] = 1.0 / measure(args.steps, b1, 1)[0]
         R.set_ascii_target(None)
 
     # per-kernel durations (HIP events on the renderer's streams) over a pass of plain frames
@@ -327,6 +357,11 @@ def main(argv=None):
     for _ in range(n_prof):
         step()
     stats_serial = R.kernel_stats()
+    # and the chains the timed region runs - `chain` frames per launch - again one chain after the other
+    stats_chain = {}
+    if chain > 1 and not gather:
+        frames(max(chain, n_prof // chain * chain), None, chain)
+        stats_chain = R.kernel_stats()
     R.set_profiling(False)
     counters = R.frame_counters()
     if not args.no_extras and rank == 0:
@@ -435,7 +470,11 @@ def main(argv=None):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32+f64",
             "data": "synthetic",
             "config": {"workload": "random mesh mulberry32(0xA5C11), %d tris, %dx%d cells, camera at origin with a per-frame yaw "
-                                   "jitter of +-%.2f rad, default lights, modal smoothing on" % (args.tris, args.cols, args.rows, YAW_JITTER),
+                                   "jitter of +-%.2f rad, default lights, modal smoothing on; %s"
+                                   % (args.tris, args.cols, args.rows, YAW_JITTER,
+                                      ("%d frames (a camera each) per library call and chain of kernel launches" % chain) if chain > 1
+                                      else "one library call and one chain of kernel launches per frame"),
+                       "frames_per_chain": chain,
                        "partition": "1 GPU" if not gather else "%d row strips, RCCL all-gather of the ASCII strips every %d frames%s"
                                     % (n_strips, max(1, args.gather_batch), " (one process, the library's group)" if native else ""),
                        "algorithmic_bytes_per_frame": ar.scenes.algorithmic_bytes(args.tris, args.cols, args.rows),
@@ -447,6 +486,12 @@ def main(argv=None):
                        "queued_records": counters},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frames_per_launch": 1,  # (achieved, traffic and the counters below are of launches that hold one frame)
+                         # the same kernel as the timed region launches it, `frames_per_chain` frames to a launch
+                         "in_chains": ({"frames_per_launch": chain, "launch_us": 1e3 * stats_chain[dom][1] / stats_chain[dom][0],
+                                        "achieved": per_launch_bytes.get(dom, 0) * chain / (1e-3 * stats_chain[dom][1] / stats_chain[dom][0]) / 1e9,
+                                        "frac": per_launch_bytes.get(dom, 0) * chain / (1e-3 * stats_chain[dom][1] / stats_chain[dom][0]) / 1e9 / HBM_PEAK_GBPS}
+                                       if stats_chain.get(dom, (0, 0))[0] else None),
                          # the kernel's reads are scattered lines: memory-side read requests per launch (PMC) over the live
                          # duration, next to the scattered-line rate a microbenchmark reaches on this chip
                          "read_requests": requests,
@@ -465,6 +510,8 @@ def main(argv=None):
             # the same for the whole frame at the measured frame rate (kernels of three frames share the chip)
             "frame_valu_busy_frac": (sum(kb[k]["SQ_ACTIVE_INST_VALU"] for k in kern_serial if k in kb) * 4.0 * fps / (N_SIMDS * clock_hz))
                                     if (kb and clock_hz and not gather) else None,  # (counters are of whole frames on one GPU)
+            # the launches of the timed region hold `frames_per_chain` frames each: their durations with the GPU to itself, per frame
+            "kernels_us_per_frame_in_chains": {k: round(1e3 * ms / n / chain, 2) for k, (n, ms) in stats_chain.items() if n} or None,
             "gather_verified": gather_ok,
             "kernels_avg_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
             "kernels_avg_us_serial": {k: round(v, 2) for k, v in kern_serial.items()},

@@ -149,6 +149,23 @@ int ar_render_async(ar_ctx *ctx, int cols, int rows);
 int ar_sync(ar_ctx *ctx);
 int ar_read(ar_ctx *ctx, uint8_t *rgba, float *depth, uint8_t *ascii, uint32_t *ids);
 
+/* Several frames in ONE chain of kernel launches: n_frames frames of cols x rows cells that differ in their camera only -
+ * cameras holds, per frame, the 16 floats of the projection and the 16 of the view matrix as ar_set_camera takes them
+ * (32 floats per frame) - are enqueued together; every kernel of the frame runs once for all of them.  Mesh, model
+ * matrix, lights, ASCII parameters, strip and options are the context's, as for ar_render_async; the context's own
+ * camera is left as it was.  A frame whose cost is launches and the hand-over between dependent kernels rather than
+ * work - a small scene, a strip of the frame on one of several GPUs - costs a fraction of that this way.  The reference
+ * renders a frame per call (RasterBackend.render, raster.js:269-362); its application calls that once per animation
+ * tick (js/main.js:364-375), so a batch is several ticks' cameras handed over at once.
+ * The frames' planes are kept apart from those of single frames: ar_read_batch copies frame `frame` (0 .. n_frames-1) of
+ * the most recent batch to host memory (any pointer may be NULL; blocks), ar_batch_device_buffer gives the device address
+ * of one of its planes (which: 0 rgba, 1 depth, 2 ascii).  While an ASCII target is set (ar_set_ascii_target) frame f's
+ * ASCII rows go to the target + f * ascii_stride bytes instead (ascii_stride is ignored otherwise).  Consecutive
+ * batches overlap on the context's frame streams as single frames do; ar_sync waits for them.  At most 256 frames a call. */
+int ar_render_batch_async(ar_ctx *ctx, int cols, int rows, int n_frames, const float *cameras, size_t ascii_stride);
+int ar_read_batch(ar_ctx *ctx, int frame, uint8_t *rgba, float *depth, uint8_t *ascii, uint32_t *ids);
+void *ar_batch_device_buffer(ar_ctx *ctx, int which, int frame);
+
 /* Read-back that does not wait: queues the device->host copies of the most recently enqueued frame's planes (each
  * pointer may be NULL, as for ar_read) behind that frame, on the stream it runs on, and returns at once with a
  * ticket; ar_wait blocks until the frame and its copies are complete, ar_poll asks without blocking (1 complete,

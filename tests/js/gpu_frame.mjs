@@ -215,6 +215,14 @@ const dump = (name, ta) => fs.writeFileSync(path.join(outDir, name), Buffer.from
     dump('burst_strip.ascii', strip);
     fl.setStrip(0, 0);
     fl.sync();
+    // the five cameras again, handed over at once: one chain of launches for all of them
+    fl.setIdOutput(false);
+    if (fl.renderBatch(meta.burst.cams, { cols, rows }) !== 5) throw new Error('renderBatch should enqueue five frames');
+    for (let k = 0; k < 5; k++) {
+      const planes = { rgba: new Uint8Array(n * 4), depth: new Float32Array(n), ascii: new Uint8Array(n) };
+      fl.readBatch(k, planes);
+      dump('batch' + k + '.rgba', planes.rgba); dump('batch' + k + '.depth', planes.depth); dump('batch' + k + '.ascii', planes.ascii);
+    }
     fl.dispose();
   }
 

@@ -674,6 +674,95 @@ def test_ascii_target_ring_with_an_odd_row_length(pkg, oracle):
         r.close()
 
 
+def test_batches_of_frames_in_one_launch_chain(pkg, oracle, golden_dir):
+    """ar_render_batch_async: n cameras, one chain of launches, every frame bit for bit the oracle's - orbit frames of the
+    cube and the icosphere (small grids, folded scan), a random soup at a grid with k_binscan, strips with and without an
+    ASCII target, smoothing off, winner ids, a batch of one, batches back to back on the frame streams, and the frames
+    that take the one-by-one road (direct path, textured)."""
+    r = pkg.Renderer(0)
+    try:
+        def check_batch(sc, cams, mode=(True, 2, 12), ids=False, label=""):
+            cols, rows = sc["cols"], sc["rows"]
+            mats = [pkg.host.camera_matrices(c, cols, rows, sc.get("pixel_aspect", 1.0)) for c in cams]
+            r.set_id_output(ids)
+            r.render_batch_async(cols, rows, pkg.Renderer.pack_cameras(mats))
+            for f, (proj, view) in enumerate(mats):
+                rgba, depth, want_ids = oracle.render(sc["vbo"], sc["idx"], proj, view, sc["lights"], cols, rows,
+                                                      uv8=sc.get("uv8"), atlas=sc.get("atlas"), model=sc.get("model"))
+                asc = oracle.quantize(rgba, cols, rows, pkg.scenes.DEFAULT_RAMP, int(mode[0]), mode[1], mode[2])
+                out = r.read_batch(f, want_ids=ids)
+                tag = "%s frame %d" % (label, f)
+                assert np.array_equal(out["rgba"], rgba), tag
+                assert np.array_equal(out["depth"].view(np.uint32), depth.view(np.uint32)), tag
+                assert np.array_equal(out["ascii"], asc), tag
+                if ids:
+                    assert np.array_equal(out["ids"], want_ids), tag
+                assert np.count_nonzero(depth < 1.0) > 20, tag
+
+        def orbit(k, n, radius=3.0, height=1.0):
+            a = 2 * math.pi * k / n
+            e = (radius * math.cos(a), height, radius * math.sin(a))
+            return {"pos": e, "yaw": math.atan2(-e[2], -e[0]), "pitch": math.asin(-e[1] / math.sqrt(e[0] ** 2 + e[1] ** 2 + e[2] ** 2))}
+
+        sc = pkg.scenes.cube_scene(0)
+        pkg.scenes.upload(r, sc)
+        check_batch(sc, [orbit(k, 12) for k in range(12)], label="cube")
+        check_batch(sc, [orbit(5, 12)], label="cube, batch of one")
+        sc = pkg.scenes.icosphere_scene(angle=0.3, cols=640, rows=360, subdiv=4, point_lights=2)
+        pkg.scenes.upload(r, sc)
+        check_batch(sc, [orbit(k, 7, 3.0, 0.4 + 0.2 * k) for k in range(5)], ids=True, label="icosphere")
+        # a soup at a grid with more than 160 bins (k_binscan in the chain), then the same mesh in a strip, smoothing off and on
+        cols, rows = 1344, 756
+        sc = pkg.scenes.random_scene(120_000, cols, rows, mesh_grid=(cols, rows))
+        pkg.scenes.upload(r, sc)
+        cams = [{"pos": (0.0, 0.0, 0.0), "yaw": 0.015 * k, "pitch": -0.01 * k} for k in range(4)]
+        check_batch(sc, cams, label="soup")
+        check_batch(sc, cams[::-1], label="soup again (the next buffer set)")
+        r.set_ascii(pkg.scenes.DEFAULT_RAMP, False, 2, 12)
+        check_batch(sc, cams[:2], mode=(False, 2, 12), label="soup, smoothing off")
+        r.set_ascii(pkg.scenes.DEFAULT_RAMP, True, 2, 12)
+        # strips into a caller's buffer: frame f's rows at target + f * stride
+        import torch
+        row0, row1, n = 200, 431, 3
+        stride = (row1 - row0) * cols
+        ring = torch.zeros(n * stride, dtype=torch.uint8, device="cuda")
+        mats = [pkg.host.camera_matrices(c, cols, rows, 1.0) for c in cams[:n]]
+        r.set_strip(row0, row1)
+        r.set_ascii_target(ring.data_ptr(), row0)
+        r.render_batch_async(cols, rows, pkg.Renderer.pack_cameras(mats), ascii_stride=stride)
+        r.sync()
+        torch.cuda.synchronize()
+        got = ring.cpu().numpy().reshape(n, row1 - row0, cols)
+        for f, (proj, view) in enumerate(mats):
+            rgba, _d, _i = oracle.render(sc["vbo"], sc["idx"], proj, view, sc["lights"], cols, rows)
+            assert np.array_equal(got[f], oracle.quantize(rgba, cols, rows, pkg.scenes.DEFAULT_RAMP, 1, 2, 12)[row0:row1]), f
+        r.set_ascii_target(None)
+        r.set_strip(0, 0)
+        # a single frame afterwards is untouched by all this (and the context's own camera is what it was)
+        _check(pkg, oracle, r, sc, label="single frame after batches")
+        # the one-by-one road: the direct path, then a textured scene
+        r.set_option("path", 1)
+        check_batch(sc, cams[:2], label="direct path")
+        r.set_option("path", 0)
+        with open(os.path.join(golden_dir, "ref_pathtrace_uv.json")) as fh:
+            case = next(c for c in json.load(fh)["cases"] if c["name"] == "default_scene_atlas32")
+        atlas = np.frombuffer(base64.b64decode(case["atlas_rgba"]), dtype=np.uint8).reshape(32, 32, 4)
+        vbo, idx, uv8 = pkg.host.build_geometry(case["scene"], textured=True)
+        tcols, trows = 120, 50
+        tcam = {"pos": (0.0, 2.5, 6.0), "yaw": -math.pi / 2, "pitch": 0.0}
+        proj, view = pkg.host.camera_matrices(tcam, tcols, trows, 0.5)
+        tsc = {"name": "poster", "vbo": vbo, "idx": idx, "uv8": uv8, "atlas": atlas, "proj": proj, "view": view,
+               "lights": pkg.host.pack_lights(case["scene"]), "cols": tcols, "rows": trows, "pixel_aspect": 0.5}
+        pkg.scenes.upload(r, tsc)
+        check_batch(tsc, [tcam, dict(tcam, yaw=-math.pi / 2 + 0.1)], label="textured")
+        with pytest.raises(pkg.AsciiRastError):
+            r.read_batch(2)
+        with pytest.raises(pkg.AsciiRastError):
+            r.render_batch_async(tcols, trows, np.zeros((0, 32), np.float32))
+    finally:
+        r.close()
+
+
 def test_group_of_one_device_gathers_the_full_frame(pkg, oracle):
     """ar_group_*: the library's own multi-GPU loop (a context and a host thread per device, strips, RCCL all-gathers in
     batches over two rings) on the one device there is here: every frame of a run - batches full and cut short, a grid

@@ -115,6 +115,10 @@ def test_node_harness_frames_match_oracle(pkg, oracle, tmp_path, rt_uniforms_of)
         asc = oracle.quantize(rgba, cols, rows, ramp, 1, 2, 12)
         assert np.count_nonzero(depth < 1.0) > 1000
         assert np.array_equal(np.fromfile(tmp_path / ("burst%d.ascii" % k), dtype=np.uint8).reshape(rows, cols), asc), k
+        # (the same camera again in the batch of five that shared one chain of launches)
+        assert np.array_equal(np.fromfile(tmp_path / ("batch%d.rgba" % k), dtype=np.uint8).reshape(rows, cols, 4), rgba), k
+        assert np.array_equal(np.fromfile(tmp_path / ("batch%d.depth" % k), dtype=np.float32).view(np.uint32).reshape(rows, cols), depth.view(np.uint32)), k
+        assert np.array_equal(np.fromfile(tmp_path / ("batch%d.ascii" % k), dtype=np.uint8).reshape(rows, cols), asc), k
         if k % 3 != 2:
             assert np.array_equal(np.fromfile(tmp_path / ("burst%d.rgba" % k), dtype=np.uint8).reshape(rows, cols, 4), rgba), k
             assert np.array_equal(np.fromfile(tmp_path / ("burst%d.depth" % k), dtype=np.float32).view(np.uint32).reshape(rows, cols),
