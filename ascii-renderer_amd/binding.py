@@ -535,7 +535,7 @@ class Renderer:
                 "bin_records": int(out[3]), "pool_overflow": int(out[4]), "tiled": int(out[5])}
 
     def set_option(self, name, value):
-        self._check(self._L.ar_set_option(self._h, {"path": 1, "pool_records": 2, "overlap": 3, "tile_rows": 4, "work_classes": 5, "fold_scan": 6}[name], int(value)))
+        self._check(self._L.ar_set_option(self._h, {"path": 1, "pool_records": 2, "overlap": 3, "tile_rows": 4, "work_classes": 5, "fold_scan": 6, "smoothing_kernel": 7}[name], int(value)))
 
 
 class Group:

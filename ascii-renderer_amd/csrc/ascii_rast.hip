@@ -999,6 +999,11 @@ int ar_set_option(ar_ctx *ctx, int option, long long value) {
             ctx->no_classes = value == 0;
             ctx->cls_area = value >= 2 ? int(value) - 1 : 0;
             return 0;
+        case AR_OPT_SMOOTHING_KERNEL:
+            if (value < 0 || value > 3) return fail(ctx, AR_E_ARG, "AR_OPT_SMOOTHING_KERNEL takes 0 .. 3");
+            ctx->ascii_path = int(value);
+            ctx->fp.ascii_path = int(value);
+            return 0;
         default:
             return fail(ctx, AR_E_ARG, "unknown option %d", option);
     }

@@ -77,6 +77,7 @@ struct ar_ctx {
     uint32_t pool_cap_option = 0;    // 0: sized from the triangle count
     int tile_shift_option = 0;       // 0: tile height chosen per frame; 3, 4, 5: fixed at 8, 16, 32 rows
     bool no_classes = false;         // AR_OPT_WORK_CLASSES 0: tile lists stay in entry order
+    int ascii_path = 0;              // AR_OPT_SMOOTHING_KERNEL
     int cls_area = 1;                // AR_OPT_WORK_CLASSES 1: rows, then width of the cell range; 2: rows, then area; 3: area, then rows
     bool no_fold = false;            // AR_OPT_FOLD_SCAN 0: k_binscan in every frame
     bool blocksum_zero[kSets] = {};  // the totals behind the count table of a set are zero (left so by a frame without k_binscan)

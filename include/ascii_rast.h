@@ -321,15 +321,24 @@ int ar_frame_counters(ar_ctx *ctx, uint32_t out[8]);
  *                        (a strip, a small grid) would otherwise have fewer than 512 tiles; 8, 16, 32 fix it.
  *   AR_OPT_WORK_CLASSES  1 (default): every tile orders its list of triangles by a work class (rows and width of the
  *                        cell range, carried in spare bits of the bin entries) so that the lanes of a wavefront get
- *                        triangles of one kind; 0: lists stay in entry order.  Same frames either way.
+ *                        triangles of one kind; 2: rows, then the triangle's area in cells instead of the width; 3: area,
+ *                        then rows (both measured within 1 % of 1); 0: lists stay in entry order.  Same frames either way.
  *   AR_OPT_FOLD_SCAN     1 (default): frames with at most 160 bins (small grids, strips) run without the scan kernel of
- *                        the binning step, its work folded into the kernels before and after it; 0: never. */
+ *                        the binning step, its work folded into the kernels before and after it; 0: never.
+ *   AR_OPT_SMOOTHING_KERNEL  which kernel runs the modal smoothing.  0 (default): the fastest one that covers the
+ *                        parameters.  For thresholds of at least half the neighbours (the reference's 12 of 24), ramps of
+ *                        at most ten glyphs and radius 1 or 2 there is a bit-sliced kernel (56 cells per lane at a time),
+ *                        taken for ar_render_batch_async and for RGBA input (ar_quantize, textured frames); single rendered
+ *                        frames and lower thresholds take a kernel that counts per cell; radius 3 and longer ramps the
+ *                        shader's two passes as written.  1: never the bit-sliced kernel; 2: only the two passes as
+ *                        written; 3: the bit-sliced kernel wherever it covers the parameters.  Same codes whichever runs. */
 #define AR_OPT_PATH 1
 #define AR_OPT_POOL_RECORDS 2
 #define AR_OPT_OVERLAP 3
 #define AR_OPT_TILE_ROWS 4
 #define AR_OPT_WORK_CLASSES 5
 #define AR_OPT_FOLD_SCAN 6
+#define AR_OPT_SMOOTHING_KERNEL 7
 int ar_set_option(ar_ctx *ctx, int option, long long value);
 
 /* ---- several GPUs in one process ------------------------------------------------------------------------

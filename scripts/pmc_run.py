@@ -10,7 +10,11 @@ R = ar.Renderer(0)
 if os.environ.get("AR_PATH") == "direct":
     R.set_option("path", 1)
 ar.scenes.upload(R, sc)
+chain = int(os.environ.get("AR_CHAIN", "0"))
 for _ in range(int(os.environ.get("AR_FRAMES", "5"))):
-    R.render_async(cols, rows)
+    if chain > 1:
+        R.render_batch_async(cols, rows, R.pack_cameras([(sc["proj"], sc["view"])] * chain))
+    else:
+        R.render_async(cols, rows)
 R.sync()
 print("done", R.frame_counters())

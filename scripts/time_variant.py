@@ -14,6 +14,24 @@ if os.environ.get("AR_TILE_ROWS"):
 if os.environ.get("AR_WORK_CLASSES"):
     R.set_option("work_classes", int(os.environ["AR_WORK_CLASSES"]))
 res = {}
+chain = int(os.environ.get("AR_CHAIN", "0"))
+if chain > 1:
+    # frames in chains of `chain` (ar_render_batch_async), the camera of the scene for every frame
+    import numpy as np
+    cams = R.pack_cameras([(sc["proj"], sc["view"])] * chain)
+    for _ in range(3): R.render_batch_async(cols, rows, cams)
+    R.sync()
+    best = 0.0
+    for rep in range(5):
+        t0 = time.perf_counter(); nb = max(4, 320 // chain)
+        for _ in range(nb): R.render_batch_async(cols, rows, cams)
+        R.sync()
+        best = max(best, nb * chain / (time.perf_counter() - t0))
+    res["fps_chains_of_%d" % chain] = round(best, 1)
+    R.set_profiling(True); R.kernel_stats(); R.set_option("overlap", 0)
+    for _ in range(8): R.render_batch_async(cols, rows, cams)
+    st = R.kernel_stats(); R.set_profiling(False); R.set_option("overlap", 1)
+    res["us_per_frame_in_chains"] = {k: round(1e3 * ms / n / chain, 2) for k, (n, ms) in st.items() if n}
 for ov in (1, 0):
     R.set_option("overlap", ov)
     for _ in range(20): R.render_async(cols, rows)

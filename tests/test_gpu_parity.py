@@ -999,6 +999,63 @@ def test_quantize_modal_vs_oracle(pkg, oracle, R):
     R.set_ascii()
 
 
+def test_bit_sliced_smoothing_vs_oracle(pkg, oracle, R):
+    """The smoothing kernel that takes 56 cells per lane (thresholds of at least half the neighbours) against the oracle's
+    two passes, and against the per-cell kernels (AR_OPT_SMOOTHING_KERNEL 1, 2): grids narrower than a word, widths that
+    are not a multiple of four, heights that are not a multiple of a block, thresholds at, above and far above half,
+    both radii, short ramps, cells with literal codes at every density, large uniform regions, and a checkerboard, where
+    every cell sees exactly half and half (more such cells than the kernel's queue holds)."""
+    rng = np.random.default_rng(17)
+    full = "@%#*+=-:. "
+    cases = [(3, 2, 2, 12, full, 0.0, "noise"), (57, 33, 2, 12, full, 0.0, "noise"), (170, 65, 2, 12, full, 0.05, "noise"),
+             (169, 31, 2, 13, full, 0.0, "noise"), (336, 64, 2, 12, full, 0.3, "noise"), (401, 90, 2, 16, "@#. ", 0.02, "noise"),
+             (223, 70, 2, 24, "@ ", 0.0, "noise"), (223, 70, 1, 4, full, 0.1, "noise"), (222, 45, 1, 5, full, 0.0, "noise"),
+             (225, 45, 1, 8, "@. ", 0.0, "noise"), (640, 360, 2, 12, full, 0.0, "blobs"), (1920, 1080, 2, 12, full, 0.001, "blobs"),
+             (200, 100, 2, 12, full, 0.0, "checker"), (200, 100, 1, 4, full, 0.0, "checker"), (168, 96, 2, 12, "@ ", 0.0, "two"),
+             (1000, 40, 2, 12, full, 1.0, "noise")]
+    levels = np.array([0, 20, 60, 90, 140, 170, 200, 225, 240, 250], dtype=np.uint8)
+    for case, (cols, rows, radius, thresh, ramp, density, kind) in enumerate(cases):
+        if kind == "noise":
+            lv = rng.choice(levels, size=(rows, cols))
+        elif kind == "two":                                                  # two values at random: counts near half are common
+            lv = rng.choice(np.array([0, 250], dtype=np.uint8), size=(rows, cols))
+        elif kind == "checker":
+            yy, xx = np.mgrid[0:rows, 0:cols]
+            lv = np.where((yy + xx) % 2 == 0, 0, 250).astype(np.uint8)
+        else:                                                                # smooth regions with noisy borders
+            yy, xx = np.mgrid[0:rows, 0:cols]
+            f = np.sin(xx / 37.0) + np.cos(yy / 23.0) + 0.35 * rng.standard_normal((rows, cols))
+            lv = levels[np.clip(((f + 2.5) * 2.0).astype(int), 0, 9)]
+        rgba = np.stack([lv, lv, lv, np.full_like(lv, 255)], axis=2)
+        ov = rng.random((rows, cols)) < density
+        rgba[ov, 3] = rng.integers(2, 255, size=int(ov.sum()))
+        R.set_ascii(ramp, True, radius, thresh)
+        want = oracle.quantize(rgba, cols, rows, ramp, 1, radius, thresh)
+        for which in (0, 1, 2):
+            R.set_option("smoothing_kernel", which)
+            got = R.quantize(rgba, cols, rows)
+            assert np.array_equal(got, want), (case, which, int(np.count_nonzero(got != want)))
+    # rendered frames (a plane of ramp indices, no literal codes): whole frames and a strip whose rows start inside a block
+    sc = pkg.scenes.icosphere_scene(cols=401, rows=131, subdiv=4, point_lights=1)
+    pkg.scenes.upload(R, sc)
+    for radius, thresh in ((2, 12), (2, 15), (1, 4)):
+        R.set_ascii(pkg.scenes.DEFAULT_RAMP, True, radius, thresh)
+        for strip in (None, (37, 90)):
+            R.set_strip(*(strip or (0, 0)))
+            frames = {}
+            for which in (1, 3):
+                R.set_option("smoothing_kernel", which)
+                frames[which] = R.render(401, 131)
+            want = oracle.quantize(frames[1]["rgba"], 401, 131, pkg.scenes.DEFAULT_RAMP, 1, radius, thresh)
+            r0, r1 = strip or (0, 131)
+            assert np.array_equal(frames[3]["ascii"][r0:r1], want[r0:r1]) and np.array_equal(frames[1]["ascii"][r0:r1], want[r0:r1])
+    R.set_strip(0, 0)
+    R.set_option("smoothing_kernel", 0)
+    R.set_ascii()
+    with pytest.raises(pkg.AsciiRastError):
+        R.set_option("smoothing_kernel", 4)
+
+
 def test_randomised_sweep_against_oracle():
     """250 random small scenes (soups with duplicates and screen-filling triangles, smooth meshes, poisoned
     input; random cameras, grids, lights, ramps, smoothing, strips, paths, pool sizes, stream schedules):
