@@ -441,10 +441,6 @@ constexpr int kBitsQueue = 1024;
 #define AR_BITS_ROWS_SINGLE 8
 #endif
 constexpr int kBitsRowsSingle = AR_BITS_ROWS_SINGLE;  // rows per lane where one frame is smoothed per launch
-#ifndef AR_BITS_ROWS_BATCH
-#define AR_BITS_ROWS_BATCH 16
-#endif
-constexpr int kBitsRowsBatch = AR_BITS_ROWS_BATCH;    // ... and where a launch takes several frames
 
 // 64 cells as two registers; three-input boolean functions by truth table (inputs a = 0xF0, b = 0xCC, c = 0xAA)
 struct Bits64 {
@@ -812,12 +808,24 @@ inline void launch_ascii_planes(const FrameParams &fp, const uint8_t *plane, uin
     const int radius = fp.mode_radius < 1 ? 1 : (fp.mode_radius > 3 ? 3 : fp.mode_radius);  // shader clamps to 1..3
     const dim3 grid((fp.cols + 127) / 128, (fp.row1 - fp.row0 + 7) / 8, unsigned(n));
     const int gbx = (fp.cols + kBitsWords * kBitsUse - 1) / (kBitsWords * kBitsUse), strip = fp.row1 - fp.row0;
-    const dim3 gbits(gbx, (strip + 2 * kBitsRowsBatch - 1) / (2 * kBitsRowsBatch), unsigned(n)), gbits1(gbx, (strip + 2 * kBitsRowsSingle - 1) / (2 * kBitsRowsSingle), 1);
+    const dim3 gbits1(gbx, (strip + 2 * kBitsRowsSingle - 1) / (2 * kBitsRowsSingle), 1);
     const bool counts = ascii_counts_domain(fp) && fp.ascii_path != 2;
     if (n > 1) {
         if (ascii_bits_domain(fp, false)) {
-            if (radius == 1) k_ascii_bits<1, kBitsRowsBatch, false, true><<<gbits, 64, 0, stream>>>(fp, plane, nullptr, ascii, fps, bs);
-            else k_ascii_bits<2, kBitsRowsBatch, false, true><<<gbits, 64, 0, stream>>>(fp, plane, nullptr, ascii, fps, bs);
+            // rows per lane: 16 do the least work per cell, but a launch of few, long wavefronts (strips, small grids)
+            // leaves most of the device idle - fewer rows per lane until there are a few thousand wavefronts
+            auto blocks = [&](int rb) { return size_t(gbx) * size_t((strip + 2 * rb - 1) / (2 * rb)) * size_t(n); };
+            const int rb = blocks(16) >= 4096 ? 16 : (blocks(8) >= 4096 ? 8 : 4);
+            const dim3 gbits(gbx, (strip + 2 * rb - 1) / (2 * rb), unsigned(n));
+            if (radius == 1) {
+                if (rb == 16) k_ascii_bits<1, 16, false, true><<<gbits, 64, 0, stream>>>(fp, plane, nullptr, ascii, fps, bs);
+                else if (rb == 8) k_ascii_bits<1, 8, false, true><<<gbits, 64, 0, stream>>>(fp, plane, nullptr, ascii, fps, bs);
+                else k_ascii_bits<1, 4, false, true><<<gbits, 64, 0, stream>>>(fp, plane, nullptr, ascii, fps, bs);
+            } else {
+                if (rb == 16) k_ascii_bits<2, 16, false, true><<<gbits, 64, 0, stream>>>(fp, plane, nullptr, ascii, fps, bs);
+                else if (rb == 8) k_ascii_bits<2, 8, false, true><<<gbits, 64, 0, stream>>>(fp, plane, nullptr, ascii, fps, bs);
+                else k_ascii_bits<2, 4, false, true><<<gbits, 64, 0, stream>>>(fp, plane, nullptr, ascii, fps, bs);
+            }
         } else if (counts) {
             if (radius == 1) k_ascii_counts<1, false, true><<<grid, 256, 0, stream>>>(fp, plane, nullptr, ascii, fps, bs);
             else k_ascii_counts<2, false, true><<<grid, 256, 0, stream>>>(fp, plane, nullptr, ascii, fps, bs);

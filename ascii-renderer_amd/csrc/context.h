@@ -644,6 +644,9 @@ int enqueue_batch(ar_ctx *ctx, int cols, int rows, int n, const float *cameras, 
         rc = plan_frame(ctx, cols, rows, again);
         if (rc) { restore(); return rc; }
         b.h_fps[f] = ctx->fp;
+        // (leaving the scan kernel out saves a frame on its own a launch, at the price of more work in k_fill; a chain
+        // of several frames pays one launch for all of them, so there the scan kernel stays)
+        if (n >= 4) b.h_fps[f].fold_scan = 0;
         b.h_fps[f].set = f;       // index of the frame's binning state in the batch's array
         b.h_fps[f].frame = uint32_t(f);
     }

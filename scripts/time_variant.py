@@ -11,8 +11,13 @@ R = ar.Renderer(0)
 ar.scenes.upload(R, sc, mode_on=not os.environ.get("AR_NO_SMOOTHING"))
 if os.environ.get("AR_TILE_ROWS"):
     R.set_option("tile_rows", int(os.environ["AR_TILE_ROWS"]))
+if os.environ.get("AR_FOLD_SCAN"):
+    R.set_option("fold_scan", int(os.environ["AR_FOLD_SCAN"]))
 if os.environ.get("AR_WORK_CLASSES"):
     R.set_option("work_classes", int(os.environ["AR_WORK_CLASSES"]))
+if os.environ.get("AR_STRIP"):      # "world,rank": that rank's strip of the frame's rows
+    world, rank = (int(x) for x in os.environ["AR_STRIP"].split(","))
+    R.set_strip(*ar.strip_rows(rows, world, rank))
 res = {}
 chain = int(os.environ.get("AR_CHAIN", "0"))
 if chain > 1:
