@@ -351,6 +351,7 @@ int plan_frame(ar_ctx *ctx, int cols, int rows, FramePlan &plan) {
         fp.cls_bits = std::min(kEntryMaskShift - fp.id_bits, kMaxClassBits);
         if (ctx->no_classes) fp.cls_bits = 0;
         fp.cls_area = ctx->cls_area;
+        fp.bin_starts = 0;
         fp.fold_scan = (nbins <= size_t(kFoldScanBins) && !ctx->no_fold) ? 1 : 0;
     }
     return 0;
@@ -646,7 +647,7 @@ int enqueue_batch(ar_ctx *ctx, int cols, int rows, int n, const float *cameras, 
         b.h_fps[f] = ctx->fp;
         // (leaving the scan kernel out saves a frame on its own a launch, at the price of more work in k_fill; a chain
         // of several frames pays one launch for all of them, so there the scan kernel stays)
-        if (n >= 4) b.h_fps[f].fold_scan = 0;
+        if (n >= 4) { b.h_fps[f].fold_scan = 0; b.h_fps[f].bin_starts = 1; }
         b.h_fps[f].set = f;       // index of the frame's binning state in the batch's array
         b.h_fps[f].frame = uint32_t(f);
     }
@@ -671,6 +672,7 @@ int enqueue_batch(ar_ctx *ctx, int cols, int rows, int n, const float *cameras, 
     if (!fp.fold_scan) {
         Stamper s(ctx, K_BINSCAN, fs);
         k_binscan<true><<<dim3(unsigned((nbins + 63) / 64), 16, N), 64 * kScanWaves, 0, fs>>>(fp, dircount, blocksum, b.d_fps, bs);
+        if (fp.bin_starts) k_binstart<true><<<dim3(1, 1, N), kSetupThreads, 0, fs>>>(fp, blocksum, b.d_state, uint32_t(b.entries), b.d_fps, bs);
     }
     {
         Stamper s(ctx, K_FILL, fs);

@@ -42,6 +42,7 @@ struct FrameParams {
                      // 3 the bit-sliced one wherever it covers the parameters
     int fold_scan;   // 1: no k_binscan in this frame - k_setup adds up the totals per bin and row block, k_fill sums the
                      // table rows before its own (frames with few bins, where that is cheaper than a kernel)
+    int bin_starts;  // 1: k_binstart has run - the bins' starts and the row-block prefixes are in place, k_fill only adds them up
     uint32_t chunk, n_groups;  // triangles per k_setup workgroup, number of those workgroups
     uint32_t frame;  // frame counter
     int set;         // buffer set of this frame (frame % kSets): binning state block, survivor slots, ...

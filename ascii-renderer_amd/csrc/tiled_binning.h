@@ -636,6 +636,55 @@ __global__ __launch_bounds__(64 * kScanWaves) void k_binscan(FrameParams fp_one,
     }
 }
 
+// Where every bin's entry array starts, once per frame instead of once per k_fill workgroup (launches over several
+// frames, FrameParams::bin_starts: there the extra launch is shared by all frames and what matters is the work saved -
+// every one of k_fill's up to a thousand workgroups otherwise reads 16 x bins totals and scans them for itself).  One
+// workgroup per frame: the 16 row-block totals per bin become, in place, "entries of earlier row blocks", the bins' totals
+// are scanned over the bins, and start / total / overflow are published for k_fill and k_tile.
+template <bool BATCH>
+__global__ __launch_bounds__(kSetupThreads) void k_binstart(FrameParams fp_one, uint32_t *__restrict__ blocksum, BinState *__restrict__ state,
+                                                            uint32_t entries_cap, const FrameParams *__restrict__ fps, BatchStrides bs) {
+    const FrameParams &fp = BATCH ? fps[blockIdx.z] : fp_one;
+    if (BATCH) blocksum += size_t(blockIdx.z) * bs.dircount;
+    __shared__ uint32_t cnt[kMaxBins];
+    __shared__ uint32_t s_wave[kSetupThreads / 64];
+    const uint32_t tid = threadIdx.x;
+    const int nbins = fp.nbx * fp.nby;
+    BinState &st = state[fp.set];
+    for (int b = int(tid); b < nbins; b += kSetupThreads) {
+        uint32_t x[16], total = 0;
+#pragma unroll
+        for (uint32_t y = 0; y < 16; y++) x[y] = blocksum[size_t(y) * nbins + b];
+#pragma unroll
+        for (uint32_t y = 0; y < 16; y++) {
+            blocksum[size_t(y) * nbins + b] = total;
+            total += x[y];
+        }
+        cnt[b] = total;
+    }
+    __syncthreads();
+    const int kRun = (nbins + kSetupThreads - 1) / kSetupThreads;
+    uint32_t run_total = 0;
+    for (int q = 0; q < kRun; q++) {
+        const int b = int(tid) * kRun + q;
+        run_total += b < nbins ? cnt[b] : 0u;
+    }
+    uint32_t n_entries;
+    uint32_t start = block_exclusive_scan<kSetupThreads / 64>(run_total, s_wave, n_entries);
+    bool overflow = false;
+    for (int q = 0; q < kRun; q++) {
+        const int b = int(tid) * kRun + q;
+        if (b >= nbins) break;
+        const uint32_t total = cnt[b];
+        const bool ok = start <= entries_cap && total <= entries_cap - start;  // the test k_fill and k_tile repeat
+        overflow = overflow || (!ok && total != 0u);
+        st.start[b] = start; st.total[b] = total;
+        start += total;
+    }
+    const int any_overflow = __syncthreads_or(overflow);
+    if (tid == 0) { st.n_entries = n_entries; st.overflow = any_overflow ? 1u : 0u; }
+}
+
 // Every workgroup first works out, from the 16 row-block totals per bin (k_binscan's blocksum), where each bin's
 // entry array starts - total per bin, exclusive scan over the bins - and where its own entries go inside it:
 // start of the bin + entries of earlier row blocks + entries of earlier workgroups of its own row block (the
@@ -665,57 +714,69 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp_one, cons
     const uint32_t rows_per_block = (fp.n_groups + 15u) / 16u;
     const uint32_t my_block = blockIdx.x / rows_per_block;
     const uint32_t n = surv_count[blockIdx.x];
-    for (int b = int(tid); b < nbins; b += kSetupThreads) {
-        uint32_t total = 0, before = 0;
-#pragma unroll
-        for (uint32_t y = 0; y < 16; y++) {
-            const uint32_t x = blocksum[size_t(y) * nbins + b];
-            total += x;
-            before += y < my_block ? x : 0u;
+    if (fp.bin_starts) {
+        // k_binstart has published the bins' starts and turned the row-block totals into prefixes
+        if (n == 0u) return;  // (nothing to store, and nothing to publish)
+        for (int b = int(tid); b < nbins; b += kSetupThreads) {
+            const uint32_t start = st.start[b], total = st.total[b];
+            base[b] = start + blocksum[size_t(my_block) * nbins + b] + dircount[size_t(blockIdx.x) * nbins + b];
+            fits[b] = (start <= entries_cap && total <= entries_cap - start) ? 1 : 0;
+            cnt[b] = 0;
         }
-        if (fp.fold_scan) {
-            // no k_binscan has run: the table holds plain counts, and the entries of the earlier workgroups of this
-            // row block are the sum of their rows (up to 63 rows of bins words from L2, sixteen loads in flight)
-            for (uint32_t g0 = my_block * rows_per_block; g0 < blockIdx.x; g0 += 16u) {
-                uint32_t x[16];
+        __syncthreads();
+    } else {
+        for (int b = int(tid); b < nbins; b += kSetupThreads) {
+            uint32_t total = 0, before = 0;
 #pragma unroll
-                for (uint32_t k = 0; k < 16; k++) x[k] = g0 + k < blockIdx.x ? dircount[size_t(g0 + k) * nbins + b] : 0u;
-#pragma unroll
-                for (uint32_t k = 0; k < 16; k++) before += x[k];
+            for (uint32_t y = 0; y < 16; y++) {
+                const uint32_t x = blocksum[size_t(y) * nbins + b];
+                total += x;
+                before += y < my_block ? x : 0u;
             }
-        } else {
-            before += dircount[size_t(blockIdx.x) * nbins + b];  // (scanned by k_binscan)
+            if (fp.fold_scan) {
+                // no k_binscan has run: the table holds plain counts, and the entries of the earlier workgroups of this
+                // row block are the sum of their rows (up to 63 rows of bins words from L2, sixteen loads in flight)
+                for (uint32_t g0 = my_block * rows_per_block; g0 < blockIdx.x; g0 += 16u) {
+                    uint32_t x[16];
+#pragma unroll
+                    for (uint32_t k = 0; k < 16; k++) x[k] = g0 + k < blockIdx.x ? dircount[size_t(g0 + k) * nbins + b] : 0u;
+#pragma unroll
+                    for (uint32_t k = 0; k < 16; k++) before += x[k];
+                }
+            } else {
+                before += dircount[size_t(blockIdx.x) * nbins + b];  // (scanned by k_binscan)
+            }
+            cnt[b] = total;
+            base[b] = before;
         }
-        cnt[b] = total;
-        base[b] = before;
+        __syncthreads();
+        // exclusive scan of the totals over the bins: each lane takes a run of consecutive bins (one bin per lane up
+        // to 256 bins, which covers 1080p)
+        const int kRun = (nbins + kSetupThreads - 1) / kSetupThreads;  // <= kMaxBins / kSetupThreads
+        uint32_t run_total = 0;
+        for (int q = 0; q < kRun; q++) {
+            const int b = int(tid) * kRun + q;
+            run_total += b < nbins ? cnt[b] : 0u;
+        }
+        uint32_t n_entries;
+        uint32_t start = block_exclusive_scan<kSetupThreads / 64>(run_total, s_wave, n_entries);
+        bool overflow = false;
+        for (int q = 0; q < kRun; q++) {
+            const int b = int(tid) * kRun + q;
+            if (b >= nbins) break;
+            const uint32_t total = cnt[b];
+            const bool ok = start <= entries_cap && total <= entries_cap - start;
+            base[b] += start;
+            fits[b] = ok ? 1 : 0;
+            overflow = overflow || (!ok && total != 0u);
+            if (blockIdx.x == 0) { st.start[b] = start; st.total[b] = total; }
+            start += total;
+        }
+        const int any_overflow = __syncthreads_or(overflow);
+        if (blockIdx.x == 0 && tid == 0) { st.n_entries = n_entries; st.overflow = any_overflow ? 1u : 0u; }
+        for (int b = int(tid); b < nbins; b += kSetupThreads) cnt[b] = 0;
+        __syncthreads();
     }
-    __syncthreads();
-    // exclusive scan of the totals over the bins: each lane takes a run of consecutive bins (one bin per lane up
-    // to 256 bins, which covers 1080p)
-    const int kRun = (nbins + kSetupThreads - 1) / kSetupThreads;  // <= kMaxBins / kSetupThreads
-    uint32_t run_total = 0;
-    for (int q = 0; q < kRun; q++) {
-        const int b = int(tid) * kRun + q;
-        run_total += b < nbins ? cnt[b] : 0u;
-    }
-    uint32_t n_entries;
-    uint32_t start = block_exclusive_scan<kSetupThreads / 64>(run_total, s_wave, n_entries);
-    bool overflow = false;
-    for (int q = 0; q < kRun; q++) {
-        const int b = int(tid) * kRun + q;
-        if (b >= nbins) break;
-        const uint32_t total = cnt[b];
-        const bool ok = start <= entries_cap && total <= entries_cap - start;
-        base[b] += start;
-        fits[b] = ok ? 1 : 0;
-        overflow = overflow || (!ok && total != 0u);
-        if (blockIdx.x == 0) { st.start[b] = start; st.total[b] = total; }
-        start += total;
-    }
-    const int any_overflow = __syncthreads_or(overflow);
-    if (blockIdx.x == 0 && tid == 0) { st.n_entries = n_entries; st.overflow = any_overflow ? 1u : 0u; }
-    for (int b = int(tid); b < nbins; b += kSetupThreads) cnt[b] = 0;
-    __syncthreads();
     const uint32_t loc_base = blockIdx.x * 2u * fp.chunk;
     for (uint32_t s = tid; s < n; s += kSetupThreads) {
         const uint32_t loc = loc_base + s;

@@ -152,9 +152,11 @@ def main():
         ok = (np.array_equal(out["ascii"][sl], asc[sl]) and np.array_equal(out["rgba"][sl], rgba[sl]) and
               np.array_equal(out["depth"][sl].view(np.uint32), depth[sl].view(np.uint32)) and np.array_equal(out["ids"][sl], ids[sl]))
         if ok and strip == (0, 0) and model is None and n % 2 == 0:
-            # the same frame twice in one launch chain (the kernels take the frame from the grid's z index)
-            R.render_batch_async(c["cols"], rows, R.pack_cameras([(c["proj"], c["view"])] * 2))
-            for f in range(2):
+            # the same frame several times in one launch chain (the kernels take the frame from the grid's z index; chains
+            # of four and more go through k_binstart)
+            nb = 5 if n % 4 == 0 else 2
+            R.render_batch_async(c["cols"], rows, R.pack_cameras([(c["proj"], c["view"])] * nb))
+            for f in range(nb):
                 got = R.read_batch(f)
                 ok = ok and np.array_equal(got["ascii"], asc) and np.array_equal(got["rgba"], rgba)
         tot_tris += c["idx"].size // 3; tot_cov += int(np.count_nonzero(ids != 0xFFFFFFFF)); tot_cells += c["cols"] * rows
