@@ -995,9 +995,8 @@ int ar_set_option(ar_ctx *ctx, int option, long long value) {
             ctx->no_fold = value == 0;
             return 0;
         case AR_OPT_WORK_CLASSES:
-            if (value < 0 || value > 3) return fail(ctx, AR_E_ARG, "AR_OPT_WORK_CLASSES takes 0 .. 3");
+            if (value != 0 && value != 1) return fail(ctx, AR_E_ARG, "AR_OPT_WORK_CLASSES takes 0 or 1");
             ctx->no_classes = value == 0;
-            ctx->cls_area = value >= 2 ? int(value) - 1 : 0;
             return 0;
         case AR_OPT_SMOOTHING_KERNEL:
             if (value < 0 || value > 3) return fail(ctx, AR_E_ARG, "AR_OPT_SMOOTHING_KERNEL takes 0 .. 3");

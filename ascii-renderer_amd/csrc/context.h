@@ -78,7 +78,6 @@ struct ar_ctx {
     int tile_shift_option = 0;       // 0: tile height chosen per frame; 3, 4, 5: fixed at 8, 16, 32 rows
     bool no_classes = false;         // AR_OPT_WORK_CLASSES 0: tile lists stay in entry order
     int ascii_path = 0;              // AR_OPT_SMOOTHING_KERNEL
-    int cls_area = 1;                // AR_OPT_WORK_CLASSES 1: rows, then width of the cell range; 2: rows, then area; 3: area, then rows
     bool no_fold = false;            // AR_OPT_FOLD_SCAN 0: k_binscan in every frame
     bool blocksum_zero[kSets] = {};  // the totals behind the count table of a set are zero (left so by a frame without k_binscan)
     float *d_tripos = nullptr;       // 9 planes x tripos_stride floats: triangle positions
@@ -350,7 +349,6 @@ int plan_frame(ar_ctx *ctx, int cols, int rows, FramePlan &plan) {
         while (fp.id_bits < kEntryMaskShift && (2ull * fp.n_tris - 1) >> fp.id_bits) fp.id_bits++;
         fp.cls_bits = std::min(kEntryMaskShift - fp.id_bits, kMaxClassBits);
         if (ctx->no_classes) fp.cls_bits = 0;
-        fp.cls_area = ctx->cls_area;
         fp.bin_starts = 0;
         fp.fold_scan = (nbins <= size_t(kFoldScanBins) && !ctx->no_fold) ? 1 : 0;
     }

@@ -37,7 +37,6 @@ struct FrameParams {
     int tshift;      // log2 of the tile height in rows (5, 4 or 3)
     int id_bits;     // bits of a bin entry that hold 2*slot + sub (enough for the mesh) ...
     int cls_bits;    // ... and, above them, so many bits of work class (0..6; what is left below the tile mask)
-    int cls_area;    // 1: the class's second key is the triangle's area in cells (k_setup's estimate), 0: the width of its cell range
     int ascii_path;  // smoothing kernel: 0 the fastest that covers the parameters, 1 never the bit-sliced one, 2 only the generic one,
                      // 3 the bit-sliced one wherever it covers the parameters
     int fold_scan;   // 1: no k_binscan in this frame - k_setup adds up the totals per bin and row block, k_fill sums the

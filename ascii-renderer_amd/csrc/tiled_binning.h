@@ -409,7 +409,6 @@ __device__ __forceinline__ void bin_range(const FrameParams &fp, int i0, int i1,
 struct Candidate {
     Screen sc;
     int i0, i1, j0, j1;
-    uint32_t area_cls;  // 0..15: window area in cells on a logarithmic scale, two steps per octave of 2 * area + 1 - a hint for the order of work
 };
 
 // Setup of the triangle with vertex positions p[0..8]: transform, near clip, cull, cell range within
@@ -431,11 +430,6 @@ __device__ __forceinline__ void triangle_setup(const FrameParams &fp, const floa
         const double det = facing_det(c[s].sc);
         if (!(det > 0.0)) continue;
         have[s] = cell_range(c[s].sc.X, c[s].sc.Y, c[s].sc.W, fp.cols, jlo, jhi, c[s].i0, c[s].i1, c[s].j0, c[s].j1);
-        // det = 2 * area * w0 w1 w2: twice the area in cells, as an integer, binned by its bit length (any value will do:
-        // it orders work, it decides nothing)
-        const float twice = float(det) * __builtin_amdgcn_rcpf((c[s].sc.W[0] * c[s].sc.W[1]) * c[s].sc.W[2]);
-        const float v = fminf(fmaxf(twice, 0.0f), 250.0f) + 1.0f;  // in [1, 251]: exponent 0..7, two steps per octave from the top mantissa bit
-        c[s].area_cls = (__float_as_uint(v) >> 22) - (127u << 1);
     }
 }
 
@@ -565,7 +559,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp_one, con
             if (!have[s]) continue;
             const uint32_t loc = loc_base + slot;
             slot++;
-            sid[loc] = (2u * t + uint32_t(s)) | (c[s].area_cls << kEntryMaskShift);  // (ids stay below 2^28: the hint rides above them)
+            sid[loc] = 2u * t + uint32_t(s);
             surv[loc] = make_uint2(uint32_t(c[s].i0) | (uint32_t(c[s].i1) << 16), uint32_t(c[s].j0) | (uint32_t(c[s].j1) << 16));
             int bx0, bx1, by0, by1;
             bin_range(fp, c[s].i0, c[s].i1, c[s].j0, c[s].j1, bx0, bx1, by0, by1);
@@ -781,8 +775,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp_one, cons
     for (uint32_t s = tid; s < n; s += kSetupThreads) {
         const uint32_t loc = loc_base + s;
         const uint2 sv = surv[loc];
-        const uint32_t id = sid[loc] & kEntryLocMask;  // 2*slot + sub: what the entries carry
-        const int area_cls = int(sid[loc] >> kEntryMaskShift);
+        const uint32_t id = sid[loc];  // 2*slot + sub: what the entries carry
         const int i0 = int(sv.x & 0xFFFFu), i1 = int(sv.x >> 16), j0 = int(sv.y & 0xFFFFu), j1 = int(sv.y >> 16);
         const int r0 = fp.rows - 1 - j1 - fp.ya, r1 = fp.rows - 1 - j0 - fp.ya;  // rows relative to the strip
         const int tx0 = i0 >> 6, tx1 = i1 >> 6, ty0 = r0 >> fp.tshift, ty1 = r1 >> fp.tshift;
@@ -793,14 +786,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_fill(FrameParams fp_one, cons
         // lane: k_tile orders every tile's list by this class so that a wavefront's triangles are of one kind.  The
         // class steers the order of the work only, never a result.
         const int hb = min(fp.cls_bits, 3), wb = fp.cls_bits - hb;
-        uint32_t cls;
-        if (fp.cls_area == 2) {        // area first (as many of its four bits as fit), rows in what is left
-            const int ab = min(fp.cls_bits, 4), rb = fp.cls_bits - ab;
-            cls = uint32_t(((area_cls >> (4 - ab)) << rb) | (min(j1 - j0 + 1, 1 << rb) - 1)) << fp.id_bits;
-        } else {
-            const int second = fp.cls_area ? (area_cls >> (4 - wb)) : (min(i1 - i0 + 1, 1 << wb) - 1);
-            cls = uint32_t(((min(j1 - j0 + 1, 1 << hb) - 1) << wb) | second) << fp.id_bits;
-        }
+        const uint32_t cls = uint32_t(((min(j1 - j0 + 1, 1 << hb) - 1) << wb) | (min(i1 - i0 + 1, 1 << wb) - 1)) << fp.id_bits;
         bool direct = false;
         for (int by = by0; by <= by1; by++)
             for (int bx = bx0; bx <= bx1; bx++) {

@@ -436,10 +436,14 @@ def main(argv=None):
         kern_serial = {k: 1e3 * ms / n for k, (n, ms) in stats_serial.items() if n}
         dom = max(kern_serial, key=lambda k: kern_serial[k])
         dom_s = kern_serial[dom] * 1e-6
-        achieved = per_launch_bytes.get(dom, 0) / dom_s / 1e9
+        # the launches of the timed region hold `chain` frames each: the roofline figures are of those launches (their
+        # duration with the GPU to itself), the launches that hold one frame are quoted beside them
+        launch_frames = chain if (chain > 1 and stats_chain.get(dom, (0, 0))[0]) else 1
+        launch_s = (1e-3 * stats_chain[dom][1] / stats_chain[dom][0]) if launch_frames > 1 else dom_s
+        achieved = per_launch_bytes.get(dom, 0) * launch_frames / launch_s / 1e9
         # Counter figures (rocprofv3 --pmc passes cannot run inside this process) come from profiles/traffic.json, which
-        # carries a fingerprint of the kernel sources it was taken on: when the sources have changed since, the line
-        # says so and carries none of them.
+        # carries a fingerprint of the kernel sources it was taken on and the frames per launch of its run: when the
+        # sources have changed since, or the launches differ, the line says so and carries none of them.
         traffic = requests = None
         valu, tj, busy = {}, {}, {}
         traffic_stale = None
@@ -448,7 +452,7 @@ def main(argv=None):
             with open(tpath) as fh:
                 tj = json.load(fh)
             here = importlib.import_module("ascii-renderer_amd.provenance").csrc_hash()
-            traffic_stale = tj.get("_csrc_hash") != here
+            traffic_stale = tj.get("_csrc_hash") != here or int(tj.get("_frames_per_launch", 1)) != launch_frames
             if traffic_stale:
                 tj = {}
             traffic = tj.get(dom)
@@ -461,7 +465,7 @@ def main(argv=None):
         # triangle record and one 4-byte entry (written once, read once) per binned (sub-triangle, bin) pair, RGBA8 +
         # depth + ramp index written and ramp index read + ASCII written per cell
         layout_bytes = args.tris * 36 + entries * (64 + 8) + args.cols * args.rows * (9 + 2)
-        measured_frame = sum(v for k, v in tj.items() if not k.startswith("_") and isinstance(v, (int, float)) and k in kern_serial)
+        measured_frame = sum(v for k, v in tj.items() if not k.startswith("_") and isinstance(v, (int, float)) and k in kern_serial) / launch_frames
         line = {
             "metric": "frames/sec at 1920x1080 cell grid, 1M tris", "value": fps, "unit": "frames/s",
             "mtri_per_s": fps * args.tris / 1e6,
@@ -486,29 +490,31 @@ def main(argv=None):
                        "queued_records": counters},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "frames_per_launch": 1,  # (achieved, traffic and the counters below are of launches that hold one frame)
-                         # the same kernel as the timed region launches it, `frames_per_chain` frames to a launch
-                         "in_chains": ({"frames_per_launch": chain, "launch_us": 1e3 * stats_chain[dom][1] / stats_chain[dom][0],
-                                        "achieved": per_launch_bytes.get(dom, 0) * chain / (1e-3 * stats_chain[dom][1] / stats_chain[dom][0]) / 1e9,
-                                        "frac": per_launch_bytes.get(dom, 0) * chain / (1e-3 * stats_chain[dom][1] / stats_chain[dom][0]) / 1e9 / HBM_PEAK_GBPS}
-                                       if stats_chain.get(dom, (0, 0))[0] else None),
+                         # achieved, traffic and the counters below are per launch; a launch holds so many frames
+                         "frames_per_launch": launch_frames, "launch_us": launch_s * 1e6,
+                         "algorithmic_bytes_per_launch": per_launch_bytes.get(dom, 0) * launch_frames,
+                         # the same kernel launched for one frame (ar_render_async), the GPU to itself
+                         "one_frame_per_launch": {"launch_us": dom_s * 1e6, "achieved": per_launch_bytes.get(dom, 0) / dom_s / 1e9,
+                                                  "frac": per_launch_bytes.get(dom, 0) / dom_s / 1e9 / HBM_PEAK_GBPS},
                          # the kernel's reads are scattered lines: memory-side read requests per launch (PMC) over the live
                          # duration, next to the scattered-line rate a microbenchmark reaches on this chip
                          "read_requests": requests,
-                         "read_request_rate_G_per_s": (requests / dom_s / 1e9) if requests else None,
+                         "read_request_rate_G_per_s": (requests / launch_s / 1e9) if requests else None,
                          "scattered_line_ceiling_G_per_s": SCATTERED_LINES_G_PER_S,
                          # what the kernel is bound by in fact: vector-ALU issue.  From counters: SQ_ACTIVE_INST_VALU (units of
                          # four cycles of one SIMD) over the SIMD-cycles of the live duration at the clock measured under load
                          # (GRBM_GUI_ACTIVE against kernel durations); and over the cycles its compute units were busy at all
                          "valu_instructions": valu.get(dom),
                          "clock_ghz_under_load": (clock_hz / 1e9) if clock_hz else None,
-                         "valu_busy_frac": (kb[dom]["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * clock_hz * dom_s))
+                         "valu_busy_frac": (kb[dom]["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMDS * clock_hz * launch_s))
                                            if (kb.get(dom) and clock_hz and not gather) else None,
                          "valu_busy_frac_while_cu_busy": (kb[dom]["SQ_ACTIVE_INST_VALU"] * 4.0 / (4.0 * kb[dom]["SQ_BUSY_CU_CYCLES"]))
-                                                         if (kb.get(dom) and not gather) else None},
+                                                         if (kb.get(dom) and not gather) else None,
+                         # HBM bytes the launch moved in fact (PMC) over its live duration: how near the memory side is
+                         "traffic_rate_GB_per_s": (traffic / launch_s / 1e9) if traffic else None},
             "traffic_stale": traffic_stale,
             # the same for the whole frame at the measured frame rate (kernels of three frames share the chip)
-            "frame_valu_busy_frac": (sum(kb[k]["SQ_ACTIVE_INST_VALU"] for k in kern_serial if k in kb) * 4.0 * fps / (N_SIMDS * clock_hz))
+            "frame_valu_busy_frac": (sum(kb[k]["SQ_ACTIVE_INST_VALU"] for k in kern_serial if k in kb) / launch_frames * 4.0 * fps / (N_SIMDS * clock_hz))
                                     if (kb and clock_hz and not gather) else None,  # (counters are of whole frames on one GPU)
             # the launches of the timed region hold `frames_per_chain` frames each: their durations with the GPU to itself, per frame
             "kernels_us_per_frame_in_chains": {k: round(1e3 * ms / n / chain, 2) for k, (n, ms) in stats_chain.items() if n} or None,

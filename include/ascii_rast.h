@@ -321,8 +321,7 @@ int ar_frame_counters(ar_ctx *ctx, uint32_t out[8]);
  *                        (a strip, a small grid) would otherwise have fewer than 512 tiles; 8, 16, 32 fix it.
  *   AR_OPT_WORK_CLASSES  1 (default): every tile orders its list of triangles by a work class (rows and width of the
  *                        cell range, carried in spare bits of the bin entries) so that the lanes of a wavefront get
- *                        triangles of one kind; 2: rows, then the triangle's area in cells instead of the width; 3: area,
- *                        then rows (both measured within 1 % of 1); 0: lists stay in entry order.  Same frames either way.
+ *                        triangles of one kind; 0: lists stay in entry order.  Same frames either way.
  *   AR_OPT_FOLD_SCAN     1 (default): frames with at most 160 bins (small grids, strips) run without the scan kernel of
  *                        the binning step, its work folded into the kernels before and after it; 0: never.
  *   AR_OPT_SMOOTHING_KERNEL  which kernel runs the modal smoothing.  0 (default): the fastest one that covers the

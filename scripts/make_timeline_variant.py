@@ -25,13 +25,11 @@ struct TimelineMark {
 namespace {
 
 constexpr uint64_t kBackgroundKey""")
-for k, (name, sig_end) in enumerate([("k_setup", "uint32_t *__restrict__ dircount) {\n"),
-                                     ("k_binscan", "uint32_t *__restrict__ blocksum) {\n"),
-                                     ("k_fill", "uint64_t *__restrict__ vis) {\n"),
-                                     ("k_tile", "uint32_t *__restrict__ ids) {\n"),
-                                     ("k_ascii_counts", "uint8_t *__restrict__ src, uint8_t *__restrict__ ascii) {\n")]):
+# (every kernel of the frame binds `fp` - its own parameters, or the frame's of a launch over several - in its first line)
+bind = "const FrameParams &fp = BATCH ? fps[blockIdx.z] : fp_one;\n"
+for k, name in enumerate(["k_setup", "k_binscan", "k_fill", "k_tile", "k_ascii_counts"]):
     i = s.index("void %s(" % name)
-    j = s.index(sig_end, i) + len(sig_end)
+    j = s.index(bind, i) + len(bind)
     s = s[:j] + "    TimelineMark timeline_mark(%d, fp.frame);\n" % k + s[j:]
 s += '''
 extern "C" int ar_debug_timeline_reset() {

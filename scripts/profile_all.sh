@@ -3,6 +3,8 @@
 # passes (each a rocprofv3 run of its own), the L2 and busy-cycle passes, then profiles/traffic.json (stamped with the
 # fingerprint of the kernel sources) and the per-round copies under profiles/.  usage: scripts/profile_all.sh <tag>
 TAG=${1:-now}
+# the counter passes render chains of so many frames (what bench.py's timed region launches), so many chains each
+export AR_CHAIN=${AR_CHAIN:-16} AR_FRAMES=${AR_FRAMES:-3}
 REPO=$(pwd)
 bash scripts/profile_round.sh $TAG > gpurun_out/profile_round_$TAG.log 2>&1 || { tail -5 gpurun_out/profile_round_$TAG.log; exit 1; }
 bash scripts/pmc_l2.sh $TAG > gpurun_out/pmc_l2_$TAG.log 2>&1 || { tail -5 gpurun_out/pmc_l2_$TAG.log; exit 1; }

@@ -23,7 +23,8 @@ def per_kernel(path, counter):
 
 src, out = sys.argv[1], sys.argv[2]
 fetch, write = per_kernel(src + "/pmc_fetch", "FETCH_SIZE"), per_kernel(src + "/pmc_write", "WRITE_SIZE")
-res = {"_note": "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; _raw holds the counters in KiB",
+res = {"_frames_per_launch": int(os.environ.get("AR_CHAIN", "1") or 1),  # frames a launch of the counter runs held (scripts/pmc_run.py)
+       "_note": "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; _raw holds the counters in KiB",
        "_raw": {k: {"FETCH_SIZE": fetch.get(k), "WRITE_SIZE": write.get(k)} for k in sorted(set(fetch) | set(write))}}
 for k in sorted(set(fetch) | set(write)):
     if k.startswith("k_"):
