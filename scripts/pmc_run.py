@@ -10,6 +10,9 @@ R = ar.Renderer(0)
 if os.environ.get("AR_PATH") == "direct":
     R.set_option("path", 1)
 ar.scenes.upload(R, sc)
+if os.environ.get("AR_STRIP"):
+    world, rank = (int(x) for x in os.environ["AR_STRIP"].split(","))
+    R.set_strip(*ar.strip_rows(rows, world, rank))
 chain = int(os.environ.get("AR_CHAIN", "0"))
 for _ in range(int(os.environ.get("AR_FRAMES", "5"))):
     if chain > 1:
