@@ -17,6 +17,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <thread>
@@ -88,8 +89,10 @@ struct ar_group {
         bool busy = false;
         int rc = 0;            // first failure of this member's thread
         char err[256] = "";
-        // the ring bookkeeping, identical in every member (each advances it by the same commands)
-        int cur = 0, filled = 0, last = -1, gathered = 0;
+        // the ring bookkeeping, identical in every member (each advances it by the same commands); what the last gather
+        // held may be asked for by the caller's thread while the member's thread is at work
+        int cur = 0, filled = 0;
+        std::atomic<int> last{-1}, gathered{0};
         // frames posted but not yet enqueued on the GPU: they go out together, as one chain of launches (ar_render_batch_async)
         std::vector<float> pending;  // 32 floats (projection, view) per frame
         int pending_cols = 0, pending_rows = 0;
@@ -128,8 +131,8 @@ void member_gather(ar_group::Member *m) {
     // (every member sends whole batches - slots a short last batch left unfilled travel as they are - so that all counts agree)
     const ncclResult_t r = g_rccl.all_gather(m->send[m->cur], m->recv[m->cur], size_t(g->batch) * g->slot_bytes, ncclUint8, m->comm, m->gather_stream);
     if (r != ncclSuccess) { member_fail(m, AR_E_HIP, "ncclAllGather", g_rccl.error_string(r)); return; }
-    m->last = m->cur;
     m->gathered = m->filled;
+    m->last = m->cur;
     m->filled = 0;
     m->cur = (m->cur + 1) % kGroupRings;
 }
@@ -348,7 +351,7 @@ int ar_group_sync(ar_group *g) {
 
 int ar_group_frames_gathered(ar_group *g) {
     if (!g || g->members.empty()) return 0;
-    return g->members[0]->last < 0 ? 0 : g->members[0]->gathered;
+    return g->members[0]->last.load() < 0 ? 0 : g->members[0]->gathered.load();
 }
 
 int ar_group_read(ar_group *g, int member, int frame, uint8_t *ascii) {
@@ -358,7 +361,7 @@ int ar_group_read(ar_group *g, int member, int frame, uint8_t *ascii) {
     if (rc) return rc;
     ar_group::Member *m = g->members[size_t(member)];
     if (m->last < 0 || frame < 0 || frame >= m->gathered)
-        return group_fail(g, AR_E_STATE, "ar_group_read: frame %d of a last batch of %d", frame, m->last < 0 ? 0 : m->gathered);
+        return group_fail(g, AR_E_STATE, "ar_group_read: frame %d of a last batch of %d", frame, m->last < 0 ? 0 : m->gathered.load());
     if (hipSetDevice(m->device) != hipSuccess) return group_fail(g, AR_E_HIP, "hipSetDevice(%d) failed", m->device);
     // recv is [device][frame of the batch][slot]: strip s of the frame sits at ((s * batch) + frame) * slot_bytes
     for (int s = 0; s < g->n; s++) {
