@@ -323,7 +323,8 @@ int ar_frame_counters(ar_ctx *ctx, uint32_t out[8]);
  *                        cell range, carried in spare bits of the bin entries) so that the lanes of a wavefront get
  *                        triangles of one kind; 0: lists stay in entry order.  Same frames either way.
  *   AR_OPT_FOLD_SCAN     1 (default): frames with at most 160 bins (small grids, strips) run without the scan kernel of
- *                        the binning step, its work folded into the kernels before and after it; 0: never.
+ *                        the binning step, its work folded into the kernels before and after it (chains of four or more
+ *                        frames, ar_render_batch_async, always keep it: they share the launch); 0: never.
  *   AR_OPT_SMOOTHING_KERNEL  which kernel runs the modal smoothing.  0 (default): the fastest one that covers the
  *                        parameters.  For thresholds of at least half the neighbours (the reference's 12 of 24), ramps of
  *                        at most ten glyphs and radius 1 or 2 there is a bit-sliced kernel (56 cells per lane at a time),
