@@ -656,7 +656,7 @@ int enqueue_batch(ar_ctx *ctx, int cols, int rows, int n, const float *cameras, 
     b.params_pending = true;
     const size_t nbins = plan.nbins;
     BatchStrides bs;
-    bs.surv = b.surv; bs.groups = size_t(kMaxGroups) + 1; bs.dircount = b.dircount; bs.entries = b.entries; bs.cells = cells; bs.ascii = ascii_step;
+    bs.surv = b.surv; bs.groups = size_t(kMaxGroups) + 1; bs.dircount = b.dircount; bs.entries = b.entries; bs.cells = cells; bs.ascii = ascii_step; bs.frames = uint32_t(n);
     uint32_t *dircount = b.d_dircount, *blocksum = b.d_dircount + b.dir_table;
     const unsigned N = unsigned(n);
     // (frames without k_binscan want the totals behind the count table at zero: k_tile leaves them so, the allocation made them so)
@@ -664,7 +664,7 @@ int enqueue_batch(ar_ctx *ctx, int cols, int rows, int n, const float *cameras, 
     b.blocksum_zero = fp.fold_scan != 0;  // (frames without k_binscan put the totals back to zero, the others leave k_binscan's there)
     {
         Stamper s(ctx, K_SETUP, fs);
-        k_setup<true><<<dim3(fp.n_groups, 1, N), kSetupThreads, nbins * sizeof(uint32_t), fs>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_box, b.d_surv, b.d_sid,
+        k_setup<true><<<dim3((fp.n_groups + 7u) / 8u * 8u * N), kSetupThreads, nbins * sizeof(uint32_t), fs>>>(fp, ctx->d_tripos, ctx->tripos_stride, ctx->d_box, b.d_surv, b.d_sid,
                                                                                               b.d_surv_count, dircount, blocksum, b.d_fps, bs);
     }
     if (!fp.fold_scan) {
@@ -681,7 +681,7 @@ int enqueue_batch(ar_ctx *ctx, int cols, int rows, int n, const float *cameras, 
         Stamper s(ctx, K_TILE, fs);
         const unsigned grid = unsigned((nbins + 7) / 8 * 8) << (2 * fp.bshift);
         auto kernel = fp.tshift == 5 ? k_tile<false, 5, true> : fp.tshift == 4 ? k_tile<false, 4, true> : k_tile<false, 3, true>;
-        kernel<<<dim3(grid, 1, N), kTileThreads, 0, fs>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_triuv, ctx->d_atlas, ctx->d_tri, ctx->d_tri_t,
+        kernel<<<dim3(grid * N), kTileThreads, 0, fs>>>(fp, ctx->d_vbo, ctx->d_idx, ctx->d_triattr, ctx->d_triuv, ctx->d_atlas, ctx->d_tri, ctx->d_tri_t,
                                                          b.d_entries, uint32_t(b.entries), b.d_state, blocksum, b.d_vis, b.d_rgba, b.d_depth, ascii_base,
                                                          b.d_ridx, b.d_ids, b.d_fps, bs);
     }

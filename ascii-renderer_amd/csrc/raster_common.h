@@ -58,6 +58,7 @@ struct BatchStrides {
     size_t entries;   // bin entries per frame
     size_t cells;     // cells per frame: visibility keys, ramp-index plane, RGBA (x 4 bytes), depth, ids
     size_t ascii;     // bytes from one frame's ASCII plane to the next (the context's planes, or the caller's target)
+    uint32_t frames;  // frames in the launch
 };
 
 // Setup record of one (sub-)triangle: edge functions, per-vertex w and clip z, cell range, key id.

@@ -478,16 +478,27 @@ __device__ __forceinline__ bool sub_triangle_screen(const FrameParams &fp, const
 // meets the survivors.  surv: the cell range of a survivor, (i0 | i1 << 16, j0 | j1 << 16); sid: 2*slot + sub -
 // all k_fill needs.  Nothing else of the setup is kept: the tiles redo it from the triangle records.
 // One triangle per lane and pass; chunk (a multiple of the workgroup size) bounds the passes of a workgroup.
-// BATCH: one launch for several frames (frame = blockIdx.z, parameters from fps, buffers at the frame's stride).
+// BATCH: one launch for several frames (parameters from fps, buffers at the frame's stride).
 template <bool BATCH>
 __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp_one, const float *__restrict__ tripos, size_t stride,
                                                          const float *__restrict__ box, uint2 *__restrict__ surv,
                                                          uint32_t *__restrict__ sid, uint32_t *__restrict__ surv_count,
                                                          uint32_t *__restrict__ dircount, uint32_t *__restrict__ blocksum,
                                                          const FrameParams *__restrict__ fps, BatchStrides bs) {
-    const FrameParams &fp = BATCH ? fps[blockIdx.z] : fp_one;
+    // Which workgroup of which frame this is.  One frame: the workgroup's own number.  Several frames in a launch: the
+    // frames of one workgroup number are neighbours in the launch order and land on the same XCD (workgroups go to the
+    // XCDs round-robin: w = ((g / 8) * frames + f) * 8 + g % 8), so that the block of positions frame 0 pulls into that
+    // XCD's L2 serves the other frames' workgroups as well - every frame reads the same 36 bytes per triangle.
+    uint32_t grp = blockIdx.x, frm = 0;
     if (BATCH) {
-        const size_t f = blockIdx.z;
+        const uint32_t q = blockIdx.x >> 3;
+        frm = q % bs.frames;
+        grp = (q / bs.frames) * 8u + (blockIdx.x & 7u);
+        if (grp >= fps[frm].n_groups) return;
+    }
+    const FrameParams &fp = BATCH ? fps[frm] : fp_one;
+    if (BATCH) {
+        const size_t f = frm;
         surv += f * bs.surv; sid += f * bs.surv; surv_count += f * bs.groups; dircount += f * bs.dircount; blocksum += f * bs.dircount;
     }
     // (LDS sized by the launch to the frame's bins, not to the most a frame can have: the frame's kernels run beside
@@ -502,7 +513,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp_one, con
     // slots are in spatial order, so a view or a strip that shows only part of the mesh leaves every workgroup
     // with about the same share of blocks that are not skipped below.
     const uint32_t total_pass = (fp.n_tris + kSetupThreads - 1) / kSetupThreads;
-    const uint32_t n_pass = blockIdx.x < total_pass ? (total_pass - blockIdx.x + fp.n_groups - 1) / fp.n_groups : 0u;
+    const uint32_t n_pass = grp < total_pass ? (total_pass - grp + fp.n_groups - 1) / fp.n_groups : 0u;
     for (int k = int(tid); k < nbins; k += kSetupThreads) hist[k] = 0;
     for (uint32_t k = tid; k < n_pass; k += kSetupThreads) outside[k] = 0x3Fu;
     __syncthreads();
@@ -514,7 +525,7 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp_one, con
     // the whole box, and every triangle in it, on its far side.
     for (uint32_t q = tid; q < 8u * n_pass; q += kSetupThreads) {
         const uint32_t pass = q >> 3;
-        const float *b = box + (size_t(pass) * fp.n_groups + blockIdx.x) * 6;
+        const float *b = box + (size_t(pass) * fp.n_groups + grp) * 6;
         const float x = b[(q & 1u) ? 3 : 0], y = b[(q & 2u) ? 4 : 1], z = b[(q & 4u) ? 5 : 2];
         float c[4], m[4];  // clip coordinates and the sums of the magnitudes of their terms
 #pragma unroll
@@ -536,12 +547,12 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp_one, con
         atomicAnd(&outside[pass], o);
     }
     __syncthreads();
-    const uint32_t loc_base = blockIdx.x * 2u * fp.chunk;
+    const uint32_t loc_base = grp * 2u * fp.chunk;
     uint32_t run = 0;  // slots handed out so far (identical in every lane)
 
     for (uint32_t pass = 0; pass < n_pass; pass++) {
         if (outside[pass] != 0u) continue;  // (the same in every lane of the workgroup)
-        const uint32_t t = (pass * fp.n_groups + blockIdx.x) * kSetupThreads + tid;  // the slot: position in the spatial order
+        const uint32_t t = (pass * fp.n_groups + grp) * kSetupThreads + tid;  // the slot: position in the spatial order
         const bool live = t < fp.n_tris;
         Candidate c[2];
         bool have[2] = {false, false}, clipped = false;
@@ -571,13 +582,13 @@ __global__ __launch_bounds__(kSetupThreads) void k_setup(FrameParams fp_one, con
     // The workgroup's row of the count table.  In a frame without k_binscan (fp.fold_scan) also its share of the totals
     // per bin and row block (16 row blocks of consecutive workgroups; blocksum is zero when such a frame starts): with
     // the triangles in spatial order a workgroup touches a handful of bins, so these are few atomics.
-    const uint32_t my_block = blockIdx.x / ((fp.n_groups + 15u) / 16u);
+    const uint32_t my_block = grp / ((fp.n_groups + 15u) / 16u);
     for (int k = int(tid); k < nbins; k += kSetupThreads) {
         const uint32_t h = hist[k];
-        dircount[size_t(blockIdx.x) * nbins + k] = h;
+        dircount[size_t(grp) * nbins + k] = h;
         if (fp.fold_scan && h != 0u) atomicAdd(&blocksum[size_t(my_block) * nbins + k], h);
     }
-    if (tid == 0) surv_count[blockIdx.x] = run;
+    if (tid == 0) surv_count[grp] = run;
 }
 
 // Column-wise exclusive prefix of the count table over the k_setup workgroups, in two levels.  The

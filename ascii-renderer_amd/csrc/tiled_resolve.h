@@ -281,7 +281,10 @@ __device__ __forceinline__ void raster_small(const FrameParams &fp, Screen sc, u
 __device__ __forceinline__ uint32_t list_slot(uint32_t p) { return p ^ ((0u - ((p >> 8) & 1u)) & 255u); }
 
 // TEX: the frame samples an atlas (texel coordinates and atlas are only read then).  SH: log2 of the tile height.
-// BATCH: one launch for several frames (frame = blockIdx.z, parameters from fps, per-frame buffers at the frame's stride).
+// BATCH: one launch for several frames (parameters from fps, per-frame buffers at the frame's stride).  The workgroups of
+// one tile in the launch's frames are neighbours in the launch order and land on the same XCD (w = ((b / 8) * frames + f)
+// * 8 + b % 8 for tile workgroup b): consecutive frames of a moving camera list mostly the same triangles in a tile, so the
+// records one frame's tile pulls into that XCD's L2 serve the other frames' as well.
 template <bool TEX, int SH, bool BATCH>
 __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp_one, const float *__restrict__ vbo,
                                               const uint32_t *__restrict__ idx, const float *__restrict__ triattr,
@@ -294,9 +297,15 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp_one, const
                                               uint8_t *__restrict__ ascii, uint8_t *__restrict__ ridx,
                                               uint32_t *__restrict__ ids, const FrameParams *__restrict__ fps, BatchStrides bs) {
     constexpr int kTileH = 1 << SH, kTileCells = kTileW * kTileH;
-    const FrameParams &fp = BATCH ? fps[blockIdx.z] : fp_one;
+    uint32_t wg = blockIdx.x, frm = 0;  // the tile's workgroup number within its frame, the frame
     if (BATCH) {
-        const size_t f = blockIdx.z;
+        const uint32_t q = blockIdx.x >> 3;
+        frm = q % bs.frames;
+        wg = (q / bs.frames) * 8u + (blockIdx.x & 7u);
+    }
+    const FrameParams &fp = BATCH ? fps[frm] : fp_one;
+    if (BATCH) {
+        const size_t f = frm;
         entries += f * bs.entries; blocksum += f * bs.dircount; vis += f * bs.cells; rgba += f * bs.cells * 4; depth += f * bs.cells;
         ascii += f * bs.ascii; ridx += f * bs.cells;
         if (ids) ids += f * bs.cells;
@@ -314,10 +323,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(FrameParams fp_one, const
     // Workgroup B = 8 * tiles_per_bin * g + 8 * k + x is tile k of bin 8 g + x.
     // (a frame without k_binscan: k_fill has used the totals per bin and row block that k_setup added up - they go
     // back to zero for the next such frame on this set of buffers)
-    if (fp.fold_scan && blockIdx.x == 0)
+    if (fp.fold_scan && wg == 0)
         for (int k = int(threadIdx.x); k < 16 * fp.nbx * fp.nby; k += kTileThreads) blocksum[k] = 0;
     const int side = 1 << fp.bshift, tiles_per_bin = side * side;
-    const int wg_group = int(blockIdx.x) / (8 * tiles_per_bin), wg_in = int(blockIdx.x) % (8 * tiles_per_bin);
+    const int wg_group = int(wg) / (8 * tiles_per_bin), wg_in = int(wg) % (8 * tiles_per_bin);
     const int bin = wg_group * 8 + (wg_in & 7), sub = wg_in >> 3;
     if (bin >= fp.nbx * fp.nby) return;
     const int tile_x = (bin % fp.nbx) * side + (sub & (side - 1)), tile_y = (bin / fp.nbx) * side + (sub >> fp.bshift);

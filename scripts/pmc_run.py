@@ -14,10 +14,17 @@ if os.environ.get("AR_STRIP"):
     world, rank = (int(x) for x in os.environ["AR_STRIP"].split(","))
     R.set_strip(*ar.strip_rows(rows, world, rank))
 chain = int(os.environ.get("AR_CHAIN", "0"))
+# a camera per frame, as bench.py's timed region has it: the scene's, turned by a yaw of 0.01 sin(2 pi k / 64) rad at frame k
+import math
+mats = [ar.host.camera_matrices(dict(sc["camera"], yaw=sc["camera"]["yaw"] + 0.01 * math.sin(2.0 * math.pi * k / 64)), cols, rows, 1.0) for k in range(64)]
+frame = 0
 for _ in range(int(os.environ.get("AR_FRAMES", "5"))):
     if chain > 1:
-        R.render_batch_async(cols, rows, R.pack_cameras([(sc["proj"], sc["view"])] * chain))
+        R.render_batch_async(cols, rows, R.pack_cameras([mats[(frame + j) % 64] for j in range(chain)]))
+        frame += chain
     else:
+        R.set_camera(*mats[frame % 64])
         R.render_async(cols, rows)
+        frame += 1
 R.sync()
 print("done", R.frame_counters())

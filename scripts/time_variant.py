@@ -21,20 +21,23 @@ if os.environ.get("AR_STRIP"):      # "world,rank": that rank's strip of the fra
 res = {}
 chain = int(os.environ.get("AR_CHAIN", "0"))
 if chain > 1:
-    # frames in chains of `chain` (ar_render_batch_async), the camera of the scene for every frame
-    import numpy as np
-    cams = R.pack_cameras([(sc["proj"], sc["view"])] * chain)
-    for _ in range(3): R.render_batch_async(cols, rows, cams)
+    # frames in chains of `chain` (ar_render_batch_async), a camera per frame as in bench.py: the scene's, turned by a
+    # yaw of 0.01 sin(2 pi k / 64) rad at frame k
+    import math
+    mats = [ar.host.camera_matrices(dict(sc["camera"], yaw=sc["camera"]["yaw"] + 0.01 * math.sin(2.0 * math.pi * k / 64)), cols, rows, 1.0) for k in range(64)]
+    packs = [R.pack_cameras([mats[(b * chain + j) % 64] for j in range(chain)]) for b in range(max(1, 64 // chain))]
+    cams = packs[0]
+    for b in range(3): R.render_batch_async(cols, rows, packs[b % len(packs)])
     R.sync()
     best = 0.0
     for rep in range(5):
         t0 = time.perf_counter(); nb = max(4, 320 // chain)
-        for _ in range(nb): R.render_batch_async(cols, rows, cams)
+        for b in range(nb): R.render_batch_async(cols, rows, packs[b % len(packs)])
         R.sync()
         best = max(best, nb * chain / (time.perf_counter() - t0))
     res["fps_chains_of_%d" % chain] = round(best, 1)
     R.set_profiling(True); R.kernel_stats(); R.set_option("overlap", 0)
-    for _ in range(8): R.render_batch_async(cols, rows, cams)
+    for b in range(8): R.render_batch_async(cols, rows, packs[b % len(packs)])
     st = R.kernel_stats(); R.set_profiling(False); R.set_option("overlap", 1)
     res["us_per_frame_in_chains"] = {k: round(1e3 * ms / n / chain, 2) for k, (n, ms) in st.items() if n}
 for ov in (1, 0):
